@@ -1,0 +1,222 @@
+"""ctypes binding of libeggshell_amd.so (the C ABI in include/eggshell_amd.h).
+
+Plumbing only: numpy arrays in, numpy arrays out.  There is NO CPU fallback;
+if the library is missing or no gfx950 device is usable the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeggshell_amd.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STALL, ERR_UNSUPPORTED, ERR_LCP_FAILED = range(7)
+JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
+F64, F32 = 0, 1
+JOINT_BALL, CONTACT_BOX = 0, 1
+
+# every symbol include/eggshell_amd.h declares
+EXPORTS = [
+    "egs_default_params", "egs_context_create", "egs_context_destroy", "egs_last_error",
+    "egs_context_synchronize", "egs_timer_start", "egs_timer_stop", "egs_kernel_time",
+    "egs_solve_blocks", "egs_problem_create", "egs_problem_destroy", "egs_problem_set_blocks",
+    "egs_problem_solve", "egs_problem_get_lambda", "egs_problem_get_accumulators",
+    "egs_problem_set_state", "egs_problem_set_constraints", "egs_problem_assemble",
+    "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
+    "egs_problem_get_stats", "egs_mixed_constraints_solve",
+]
+
+
+class SolveParams(C.Structure):
+    _fields_ = [("method", C.c_int32), ("max_iters", C.c_int32), ("check_every", C.c_int32),
+                ("reserved", C.c_int32), ("omega", C.c_double), ("cfm", C.c_double),
+                ("tol", C.c_double)]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("status", C.c_int32), ("residual", C.c_double),
+                ("n_islands", C.c_int32), ("n_tiles", C.c_int32), ("n_global", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class EgsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("eggshell_amd status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                LIB_PATH + " is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.egs_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def params(method=GAUSS_SEIDEL, max_iters=500, tol=1e-9, cfm=0.0, omega=1.5, check_every=1):
+    return SolveParams(method, max_iters, check_every, 0, omega, cfm, tol)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        st = load().egs_context_create(C.c_int(device), C.byref(self.h))
+        if st != OK:
+            self.h = C.c_void_p()
+            raise EgsError(st, "egs_context_create failed (no usable gfx950 device?)")
+
+    def check(self, st):
+        if st != OK:
+            raise EgsError(st, load().egs_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            load().egs_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(load().egs_context_synchronize(self.h))
+
+    def timer_start(self):
+        self.check(load().egs_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self.check(load().egs_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def kernel_time(self, reset=True):
+        s = C.c_double(0); n = C.c_int64(0)
+        self.check(load().egs_kernel_time(self.h, C.byref(s), C.byref(n), C.c_int(1 if reset else 0)))
+        return s.value, n.value
+
+    def solve_blocks(self, Minv, body0, body1, J0, J1, is_eq, lo, hi, rhs, prm, precision=F64):
+        """sparse::{Jacobi,GaussSeidel,SOR}Iteration on flat arrays (entry 1)."""
+        Minv, J0, J1, lo, hi, rhs = map(_f64, (Minv, J0, J1, lo, hi, rhs))
+        body0, body1, is_eq = _i32(body0), _i32(body1), _u8(is_eq)
+        n = Minv.reshape(-1, 36).shape[0]
+        m = body0.shape[0]
+        x = np.zeros(3 * m)
+        st = SolveStats()
+        self.check(load().egs_solve_blocks(self.h, C.c_int32(n), _p(Minv), C.c_int32(m), _p(body0),
+                                           _p(body1), _p(J0), _p(J1), _p(is_eq), _p(lo), _p(hi), _p(rhs),
+                                           C.byref(prm), C.c_int32(precision), _p(x), C.byref(st)))
+        return x, st
+
+    def mixed_constraints_solve(self, A, b, Ceq, lo, hi, use_bounds=0):
+        A, b, lo, hi = map(_f64, (A, b, lo, hi))
+        Ceq = _u8(Ceq)
+        N = b.shape[0]
+        x = np.zeros(N); w = np.zeros(N); ok = C.c_int32(0); piv = C.c_int32(0)
+        st = load().egs_mixed_constraints_solve(self.h, C.c_int32(N), _p(A), _p(b), _p(Ceq), _p(lo), _p(hi),
+                                                C.c_int32(use_bounds), _p(x), _p(w), C.byref(ok), C.byref(piv))
+        if st not in (OK, ERR_LCP_FAILED):
+            self.check(st)
+        return bool(ok.value), x, w, piv.value
+
+
+class Problem:
+    """Device-resident ensemble (or batch of ensembles)."""
+
+    def __init__(self, ctx, n_bodies, body0, body1, precision=F64):
+        self.ctx = ctx
+        self.body0, self.body1 = _i32(body0), _i32(body1)
+        self.n, self.m = int(n_bodies), int(self.body0.shape[0])
+        self.h = C.c_void_p()
+        ctx.check(load().egs_problem_create(ctx.h, C.c_int32(self.n), C.c_int32(self.m), _p(self.body0),
+                                            _p(self.body1), C.c_int32(precision), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            load().egs_problem_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_blocks(self, Minv=None, J0=None, J1=None, is_eq=None, lo=None, hi=None, rhs=None):
+        a = [_f64(Minv), _f64(J0), _f64(J1), _u8(is_eq), _f64(lo), _f64(hi), _f64(rhs)]
+        self.ctx.check(load().egs_problem_set_blocks(self.h, *[_p(v) for v in a]))
+
+    def set_state(self, pos=None, R=None, v=None, w=None, Minv=None, f_ext=None):
+        a = [_f64(pos), _f64(R), _f64(v), _f64(w), _f64(Minv), _f64(f_ext)]
+        self.ctx.check(load().egs_problem_set_state(self.h, *[_p(v_) for v_ in a]))
+
+    def set_constraints(self, kind, data):
+        kind, data = _i32(kind), _f64(data)
+        self.ctx.check(load().egs_problem_set_constraints(self.h, _p(kind), _p(data)))
+
+    def assemble(self, dt, erp=0.2):
+        self.ctx.check(load().egs_problem_assemble(self.h, C.c_double(dt), C.c_double(erp)))
+
+    def solve(self, prm, want_stats=True):
+        st = SolveStats()
+        self.ctx.check(load().egs_problem_solve(self.h, C.byref(prm), C.byref(st) if want_stats else None))
+        return st
+
+    def step(self, dt, erp, prm, want_stats=False):
+        st = SolveStats()
+        self.ctx.check(load().egs_problem_step(self.h, C.c_double(dt), C.c_double(erp), C.byref(prm),
+                                               C.byref(st) if want_stats else None))
+        return st
+
+    def stats(self):
+        st = SolveStats()
+        self.ctx.check(load().egs_problem_get_stats(self.h, C.byref(st)))
+        return st
+
+    def lambda_(self):
+        x = np.zeros(3 * self.m)
+        self.ctx.check(load().egs_problem_get_lambda(self.h, _p(x)))
+        return x
+
+    def accumulators(self):
+        a = np.zeros((self.n, 6))
+        self.ctx.check(load().egs_problem_get_accumulators(self.h, _p(a)))
+        return a
+
+    def velocity(self):
+        v = np.zeros((self.n, 6))
+        self.ctx.check(load().egs_problem_get_velocity(self.h, _p(v)))
+        return v
+
+    def blocks(self):
+        m = self.m
+        J0 = np.zeros((m, 18)); J1 = np.zeros((m, 18)); is_eq = np.zeros(3 * m, np.uint8)
+        lo = np.zeros(3 * m); hi = np.zeros(3 * m); rhs = np.zeros(3 * m); err = np.zeros(3 * m)
+        self.ctx.check(load().egs_problem_get_blocks(self.h, _p(J0), _p(J1), _p(is_eq), _p(lo), _p(hi),
+                                                     _p(rhs), _p(err)))
+        return J0, J1, is_eq, lo, hi, rhs, err

@@ -1,0 +1,661 @@
+// capi.cpp -- the extern "C" boundary (include/eggshell_amd.h): contexts,
+// device-resident problems, solve driver.  No torch types, no CPU fallback:
+// without a usable HIP device every entry fails with EGS_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/eggshell_amd.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace egs;
+
+struct egs_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::string error;
+  // hipEvent pairs around every solve-kernel launch
+  std::vector<hipEvent_t> kev;
+  size_t kev_used = 0;
+};
+
+namespace {
+
+constexpr size_t kEventPairs = 4096;
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+void hip_check(hipError_t e, const char *what) {
+  if (e != hipSuccess) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    throw HipError(buf);
+  }
+}
+#define HIPCHK(call) hip_check((call), #call)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  void alloc(size_t n) {
+    release();
+    count = n;
+    if (n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+template <typename T>
+void upload(DevBuf<T> &d, const T *src, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  HIPCHK(hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // src may be a temporary
+}
+
+}  // namespace
+
+struct egs_problem {
+  egs_context *ctx = nullptr;
+  int n = 0, m = 0, precision = EGS_F64;
+  Plan plan;
+  // plan
+  DevBuf<LaneDesc> lanes;
+  DevBuf<int32_t> tile_nslots, tile_slot_off, slot_body;
+  DevBuf<GlobalDesc> gcons;
+  DevBuf<uint32_t> gtickets;
+  // topology + state (fp64)
+  DevBuf<int32_t> body0, body1, kind;
+  DevBuf<double> pos, R, v, w, Minv_d, f_ext, data, err, v6, res_partials;
+  // solver arrays, REAL = double or float (byte buffers)
+  DevBuf<unsigned char> Minv_r, J0, J1, lo, hi, rhs, x, acc, wres;
+  DevBuf<unsigned char> gB0, gB1, gD, gden, gdx;  // cross-workgroup workspace
+  DevBuf<uint8_t> is_eq;
+  DevBuf<int32_t> error_flag;
+  bool have_blocks = false, have_state = false, have_constraints = false, minv_r_valid = false;
+  int last_iterations = 0;
+  size_t real_size() const { return precision == EGS_F32 ? sizeof(float) : sizeof(double); }
+};
+
+namespace {
+
+egs_status fail(egs_context *ctx, egs_status st, const std::string &msg) {
+  if (ctx) ctx->error = msg;
+  return st;
+}
+
+template <typename F>
+egs_status guarded(egs_context *ctx, F &&f) {
+  try {
+    return f();
+  } catch (const HipError &e) {
+    return fail(ctx, EGS_ERR_HIP, e.what());
+  } catch (const std::invalid_argument &e) {
+    return fail(ctx, EGS_ERR_INVALID, e.what());
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, EGS_ERR_HIP, "host allocation failed");
+  } catch (const std::exception &e) {
+    return fail(ctx, EGS_ERR_HIP, e.what());
+  }
+}
+
+void upload_real(egs_problem *p, DevBuf<unsigned char> &dst, const double *src, size_t count) {
+  if (!src || count == 0) return;
+  hipStream_t s = p->ctx->stream;
+  if (p->precision == EGS_F32) {
+    std::vector<float> tmp(count);
+    for (size_t i = 0; i < count; ++i) tmp[i] = (float)src[i];
+    HIPCHK(hipMemcpyAsync(dst.p, tmp.data(), count * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  } else {
+    HIPCHK(hipMemcpyAsync(dst.p, src, count * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+}
+
+void download_real(egs_problem *p, const DevBuf<unsigned char> &src, double *dst, size_t count) {
+  if (!dst || count == 0) return;
+  hipStream_t s = p->ctx->stream;
+  if (p->precision == EGS_F32) {
+    std::vector<float> tmp(count);
+    HIPCHK(hipMemcpyAsync(tmp.data(), src.p, count * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+  } else {
+    HIPCHK(hipMemcpyAsync(dst, src.p, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+}
+
+void ensure_minv_real(egs_problem *p) {
+  if (p->minv_r_valid) return;
+  const int count = p->n * 36;
+  if (p->precision == EGS_F32)
+    launch_convert_minv<float>(count, p->Minv_d.p, reinterpret_cast<float *>(p->Minv_r.p), p->ctx->stream);
+  else
+    launch_convert_minv<double>(count, p->Minv_d.p, reinterpret_cast<double *>(p->Minv_r.p), p->ctx->stream);
+  p->minv_r_valid = true;
+}
+
+void record_kernel_event(egs_context *ctx, bool begin) {
+  if (ctx->kev.empty()) return;
+  const size_t pair = ctx->kev_used % kEventPairs;
+  HIPCHK(hipEventRecord(ctx->kev[2 * pair + (begin ? 0 : 1)], ctx->stream));
+  if (!begin) ++ctx->kev_used;
+}
+
+template <typename REAL>
+void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweeps, int resume) {
+  egs_context *ctx = p->ctx;
+  record_kernel_event(ctx, true);
+  if (p->plan.n_tiles > 0) {
+    SolveArgs<REAL> a;
+    a.lanes = p->lanes.p;
+    a.tile_nslots = p->tile_nslots.p;
+    a.tile_slot_off = p->tile_slot_off.p;
+    a.slot_body = p->slot_body.p;
+    a.Minv = reinterpret_cast<const REAL *>(p->Minv_r.p);
+    a.J0 = reinterpret_cast<const REAL *>(p->J0.p);
+    a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
+    a.is_eq = p->is_eq.p;
+    a.lo = reinterpret_cast<const REAL *>(p->lo.p);
+    a.hi = reinterpret_cast<const REAL *>(p->hi.p);
+    a.rhs = reinterpret_cast<const REAL *>(p->rhs.p);
+    a.x = reinterpret_cast<REAL *>(p->x.p);
+    a.acc = reinterpret_cast<REAL *>(p->acc.p);
+    a.wres = reinterpret_cast<REAL *>(p->wres.p);
+    a.error_flag = p->error_flag.p;
+    a.cfm = cfm;
+    a.kscale = kscale;
+    a.sweeps = sweeps;
+    a.resume = resume;
+    a.max_slots = p->plan.max_slots;
+    a.spin_limit = kSpinLimit;
+    launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+  }
+  if (!p->plan.global.empty()) {
+    GlobalArgs<REAL> g;
+    g.cons = p->gcons.p;
+    g.mg = (int)p->plan.global.size();
+    g.n_bodies = p->n; g.pad0 = 0; g.per_lane = 1; g.mode = 0;
+    g.B0 = reinterpret_cast<REAL *>(p->gB0.p); g.B1 = reinterpret_cast<REAL *>(p->gB1.p);
+    g.D = reinterpret_cast<REAL *>(p->gD.p); g.den = reinterpret_cast<REAL *>(p->gden.p);
+    g.dx = reinterpret_cast<REAL *>(p->gdx.p);
+    g.Minv = reinterpret_cast<const REAL *>(p->Minv_r.p);
+    g.J0 = reinterpret_cast<const REAL *>(p->J0.p);
+    g.J1 = reinterpret_cast<const REAL *>(p->J1.p);
+    g.is_eq = p->is_eq.p;
+    g.lo = reinterpret_cast<const REAL *>(p->lo.p);
+    g.hi = reinterpret_cast<const REAL *>(p->hi.p);
+    g.rhs = reinterpret_cast<const REAL *>(p->rhs.p);
+    g.x = reinterpret_cast<REAL *>(p->x.p);
+    g.acc = reinterpret_cast<REAL *>(p->acc.p);
+    g.wres = reinterpret_cast<REAL *>(p->wres.p);
+    g.tickets = p->gtickets.p;
+    g.error_flag = p->error_flag.p;
+    g.cfm = cfm;
+    g.kscale = kscale;
+    g.sweeps = sweeps;
+    g.resume = resume;
+    g.method = method;
+    g.spin_limit = kSpinLimit;
+    launch_global_solve<REAL>(g, ctx->stream);
+  }
+  record_kernel_event(ctx, false);
+  HIPCHK(hipGetLastError());
+}
+
+void launch_solve(egs_problem *p, const egs_solve_params &prm, int sweeps, int resume) {
+  ensure_minv_real(p);
+  if (p->precision == EGS_F32) {
+    const float ks = prm.method == EGS_SOR ? 1.0f / (float)prm.omega : 1.0f;
+    launch_solve_t<float>(p, prm.method, (float)prm.cfm, ks, sweeps, resume);
+  } else {
+    const double ks = prm.method == EGS_SOR ? 1.0 / prm.omega : 1.0;
+    launch_solve_t<double>(p, prm.method, prm.cfm, ks, sweeps, resume);
+  }
+}
+
+void launch_residual(egs_problem *p) {
+  const int rows = 3 * p->m;
+  hipStream_t s = p->ctx->stream;
+  if (p->precision == EGS_F32)
+    launch_residual_partials<float>(rows, reinterpret_cast<const float *>(p->wres.p), reinterpret_cast<const float *>(p->x.p),
+                                    reinterpret_cast<const float *>(p->lo.p), reinterpret_cast<const float *>(p->hi.p),
+                                    p->is_eq.p, p->res_partials.p, kResidualBlocks, s);
+  else
+    launch_residual_partials<double>(rows, reinterpret_cast<const double *>(p->wres.p), reinterpret_cast<const double *>(p->x.p),
+                                     reinterpret_cast<const double *>(p->lo.p), reinterpret_cast<const double *>(p->hi.p),
+                                     p->is_eq.p, p->res_partials.p, kResidualBlocks, s);
+}
+
+// synchronises; returns the reference's residual metric and the error flag
+double read_residual(egs_problem *p, int *err_flag) {
+  double part[4 * kResidualBlocks];
+  int32_t flag = 0;
+  hipStream_t s = p->ctx->stream;
+  HIPCHK(hipMemcpyAsync(part, p->res_partials.p, sizeof part, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&flag, p->error_flag.p, sizeof flag, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  double sum[4] = {0, 0, 0, 0};
+  for (int b = 0; b < kResidualBlocks; ++b)
+    for (int k = 0; k < 4; ++k) sum[k] += part[4 * b + k];
+  if (err_flag) *err_flag = flag;
+  return std::sqrt(sum[0]) + (std::sqrt(sum[1]) + std::sqrt(sum[2]) + std::sqrt(sum[3]));
+}
+
+egs_status validate_params(egs_context *ctx, const egs_solve_params *prm) {
+  if (!prm) return fail(ctx, EGS_ERR_INVALID, "params is NULL");
+  if (prm->method < 0 || prm->method > 2) return fail(ctx, EGS_ERR_INVALID, "unknown method");
+  if (prm->max_iters < 0) return fail(ctx, EGS_ERR_INVALID, "max_iters < 0");
+  if (prm->method == EGS_SOR && !(prm->omega > 0 && prm->omega < 2))
+    return fail(ctx, EGS_ERR_INVALID, "SOR needs 0 < omega < 2 (sparse_iterations.cc:15)");
+  return EGS_OK;
+}
+
+void fill_stats(egs_problem *p, egs_solve_stats *st) {
+  st->n_islands = p->plan.n_islands;
+  st->n_tiles = p->plan.n_tiles;
+  st->n_global = (int32_t)p->plan.global.size();
+  st->reserved = 0;
+}
+
+// The solve driver: sparse_iterations.cc:148-226.
+egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats *stats) {
+  egs_context *ctx = p->ctx;
+  if (egs_status st = validate_params(ctx, prm)) return st;
+  if (!p->have_blocks) return fail(ctx, EGS_ERR_INVALID, "no system uploaded (set_blocks or assemble first)");
+  if (p->m == 0) {  // sparse_iterations.cc:152-154
+    p->last_iterations = 0;
+    if (stats) { std::memset(stats, 0, sizeof *stats); fill_stats(p, stats); }
+    return EGS_OK;
+  }
+  HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream));
+  if (!(prm->tol > 0)) {
+    launch_solve(p, *prm, prm->max_iters, 0);
+    launch_residual(p);
+    p->last_iterations = prm->max_iters;
+    if (stats) {
+      int flag = 0;
+      stats->residual = read_residual(p, &flag);
+      stats->iterations = prm->max_iters;
+      stats->status = flag ? EGS_ERR_STALL : EGS_OK;
+      fill_stats(p, stats);
+      if (flag) return fail(ctx, EGS_ERR_STALL, "device ordering wait timed out");
+    }
+    return EGS_OK;
+  }
+  // tol > 0: x0 = rhs, residual before iterating, then chunks of check_every
+  const int every = prm->check_every > 0 ? prm->check_every : 1;
+  int it = 0, flag = 0;
+  launch_solve(p, *prm, 0, 0);
+  launch_residual(p);
+  double err = read_residual(p, &flag);
+  while (!flag && err > prm->tol && it < prm->max_iters) {
+    const int chunk = std::min(every, prm->max_iters - it);
+    launch_solve(p, *prm, chunk, 1);
+    launch_residual(p);
+    err = read_residual(p, &flag);
+    it += chunk;
+  }
+  p->last_iterations = it;
+  if (stats) {
+    stats->residual = err;
+    stats->iterations = it;
+    stats->status = flag ? EGS_ERR_STALL : EGS_OK;
+    fill_stats(p, stats);
+  }
+  if (flag) return fail(ctx, EGS_ERR_STALL, "device ordering wait timed out");
+  return EGS_OK;
+}
+
+void do_assemble(egs_problem *p, double dt, double erp) {
+  AssembleArgs a;
+  a.n = p->n; a.m = p->m;
+  a.pos = p->pos.p; a.R = p->R.p; a.v = p->v.p; a.w = p->w.p;
+  a.Minv = p->Minv_d.p; a.f_ext = p->f_ext.p;
+  a.kind = p->kind.p; a.body0 = p->body0.p; a.body1 = p->body1.p;
+  a.data = p->data.p;
+  a.dt = dt; a.erp = erp;
+  a.J0 = p->J0.p; a.J1 = p->J1.p; a.lo = p->lo.p; a.hi = p->hi.p; a.rhs = p->rhs.p;
+  a.err = p->err.p; a.is_eq = p->is_eq.p;
+  if (p->precision == EGS_F32) launch_assemble<float>(a, p->ctx->stream);
+  else launch_assemble<double>(a, p->ctx->stream);
+  HIPCHK(hipGetLastError());
+  p->have_blocks = true;
+}
+
+void do_velocity(egs_problem *p, double dt) {
+  if (p->precision == EGS_F32)
+    launch_velocity<float>(p->n, p->v.p, p->w.p, p->Minv_d.p, p->f_ext.p, reinterpret_cast<const float *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
+  else
+    launch_velocity<double>(p->n, p->v.p, p->w.p, p->Minv_d.p, p->f_ext.p, reinterpret_cast<const double *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
+  HIPCHK(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+void egs_default_params(egs_solve_params *p) {
+  if (!p) return;
+  p->method = EGS_GAUSS_SEIDEL;
+  p->max_iters = 500;   // sparse_iterations.cc:19
+  p->check_every = 1;
+  p->reserved = 0;
+  p->omega = 1.5;       // sparse_iterations.cc:15
+  p->cfm = 0.0;
+  p->tol = 1e-9;        // constants.h:5
+}
+
+egs_status egs_context_create(int device_index, egs_context **out) {
+  if (!out) return EGS_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return EGS_ERR_NO_DEVICE;
+  if (device_index < 0 || device_index >= count) return EGS_ERR_INVALID;
+  egs_context *ctx = new (std::nothrow) egs_context;
+  if (!ctx) return EGS_ERR_HIP;
+  ctx->device = device_index;
+  egs_status st = guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(device_index));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ctx->t0));
+    HIPCHK(hipEventCreate(&ctx->t1));
+    ctx->kev.resize(2 * kEventPairs, nullptr);
+    for (auto &e : ctx->kev) HIPCHK(hipEventCreate(&e));
+    return EGS_OK;
+  });
+  if (st != EGS_OK) {
+    egs_context_destroy(ctx);
+    return st;
+  }
+  *out = ctx;
+  return EGS_OK;
+}
+
+void egs_context_destroy(egs_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto e : ctx->kev) if (e) (void)hipEventDestroy(e);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *egs_last_error(const egs_context *ctx) { return ctx ? ctx->error.c_str() : "no context"; }
+
+egs_status egs_context_synchronize(egs_context *ctx) {
+  if (!ctx) return EGS_ERR_INVALID;
+  return guarded(ctx, [&]() -> egs_status { HIPCHK(hipStreamSynchronize(ctx->stream)); return EGS_OK; });
+}
+
+egs_status egs_timer_start(egs_context *ctx) {
+  if (!ctx) return EGS_ERR_INVALID;
+  return guarded(ctx, [&]() -> egs_status { HIPCHK(hipEventRecord(ctx->t0, ctx->stream)); return EGS_OK; });
+}
+
+egs_status egs_timer_stop(egs_context *ctx, float *elapsed_ms) {
+  if (!ctx || !elapsed_ms) return EGS_ERR_INVALID;
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipEventRecord(ctx->t1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->t1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return EGS_OK;
+  });
+}
+
+egs_status egs_kernel_time(egs_context *ctx, double *sum_ms, int64_t *launches, int reset) {
+  if (!ctx) return EGS_ERR_INVALID;
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t cnt = std::min(ctx->kev_used, kEventPairs);
+    double sum = 0;
+    for (size_t i = 0; i < cnt; ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->kev[2 * i], ctx->kev[2 * i + 1]));
+      sum += ms;
+    }
+    if (sum_ms) *sum_ms = sum;
+    if (launches) *launches = (int64_t)cnt;
+    if (reset) ctx->kev_used = 0;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0,
+                              const int32_t *body1, int32_t precision, egs_problem **out) {
+  if (!ctx || !out) return EGS_ERR_INVALID;
+  *out = nullptr;
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return fail(ctx, EGS_ERR_INVALID, "bad sizes / NULL topology");
+  if (precision != EGS_F64 && precision != EGS_F32) return fail(ctx, EGS_ERR_INVALID, "unknown precision");
+  for (int i = 0; i < m; ++i)
+    if (body0[i] >= 0 && body0[i] == body1[i])
+      return fail(ctx, EGS_ERR_INVALID, "constraint with the same body on both sides");
+  egs_problem *p = new (std::nothrow) egs_problem;
+  if (!p) return fail(ctx, EGS_ERR_HIP, "host allocation failed");
+  p->ctx = ctx; p->n = n; p->m = m; p->precision = precision;
+  egs_status st = guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    p->plan = build_plan(n, m, body0, body1, 256);
+    const Plan &pl = p->plan;
+    hipStream_t s = ctx->stream;
+    p->lanes.alloc(pl.lanes.size()); upload(p->lanes, pl.lanes.data(), pl.lanes.size(), s);
+    p->tile_nslots.alloc(pl.tile_nslots.size()); upload(p->tile_nslots, pl.tile_nslots.data(), pl.tile_nslots.size(), s);
+    p->tile_slot_off.alloc(pl.tile_slot_off.size()); upload(p->tile_slot_off, pl.tile_slot_off.data(), pl.tile_slot_off.size(), s);
+    p->slot_body.alloc(pl.slot_body.size()); upload(p->slot_body, pl.slot_body.data(), pl.slot_body.size(), s);
+    p->gcons.alloc(pl.global.size()); upload(p->gcons, pl.global.data(), pl.global.size(), s);
+    p->gtickets.alloc((size_t)(n > 0 ? n : 1));
+    {
+      const size_t mg = pl.global.size(), rsz = p->real_size();
+      p->gB0.alloc(mg * 18 * rsz); p->gB1.alloc(mg * 18 * rsz); p->gD.alloc(mg * 9 * rsz);
+      p->gden.alloc(mg * 3 * rsz); p->gdx.alloc(mg * 3 * rsz);
+    }
+    p->body0.alloc(m); upload(p->body0, body0, m, s);
+    p->body1.alloc(m); upload(p->body1, body1, m, s);
+    const size_t rs = p->real_size();
+    const size_t nn = (size_t)(n > 0 ? n : 1), mm = (size_t)(m > 0 ? m : 1);
+    p->kind.alloc(mm); p->data.alloc(mm * 7);
+    p->pos.alloc(nn * 3); p->R.alloc(nn * 9); p->v.alloc(nn * 3); p->w.alloc(nn * 3);
+    p->Minv_d.alloc(nn * 36); p->f_ext.alloc(nn * 6); p->err.alloc(mm * 3); p->v6.alloc(nn * 6);
+    p->res_partials.alloc(4 * kResidualBlocks);
+    p->Minv_r.alloc(nn * 36 * rs);
+    p->J0.alloc(mm * 18 * rs); p->J1.alloc(mm * 18 * rs);
+    p->lo.alloc(mm * 3 * rs); p->hi.alloc(mm * 3 * rs); p->rhs.alloc(mm * 3 * rs);
+    p->x.alloc(mm * 3 * rs); p->acc.alloc(nn * 6 * rs); p->wres.alloc(mm * 3 * rs);
+    p->is_eq.alloc(mm * 3);
+    p->error_flag.alloc(1);
+    HIPCHK(hipMemsetAsync(p->acc.p, 0, nn * 6 * rs, s));
+    HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
+    HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
+    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
+    HIPCHK(hipStreamSynchronize(s));
+    return EGS_OK;
+  });
+  if (st != EGS_OK) { delete p; return st; }
+  *out = p;
+  return EGS_OK;
+}
+
+void egs_problem_destroy(egs_problem *p) {
+  if (!p) return;
+  if (p->ctx && p->ctx->stream) (void)hipStreamSynchronize(p->ctx->stream);
+  delete p;
+}
+
+egs_status egs_problem_set_blocks(egs_problem *p, const double *Minv, const double *J0, const double *J1,
+                                  const uint8_t *is_eq, const double *lo, const double *hi, const double *rhs) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    const size_t n = p->n, m = p->m;
+    if (Minv && n) { upload(p->Minv_d, Minv, n * 36, p->ctx->stream); p->minv_r_valid = false; }
+    upload_real(p, p->J0, J0, m * 18);
+    upload_real(p, p->J1, J1, m * 18);
+    if (is_eq && m) upload(p->is_eq, is_eq, m * 3, p->ctx->stream);
+    upload_real(p, p->lo, lo, m * 3);
+    upload_real(p, p->hi, hi, m * 3);
+    upload_real(p, p->rhs, rhs, m * 3);
+    p->have_blocks = true;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_solve(egs_problem *p, const egs_solve_params *params, egs_solve_stats *stats) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status { return do_solve(p, params, stats); });
+}
+
+egs_status egs_problem_get_lambda(egs_problem *p, double *x) {
+  if (!p || !x) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status { download_real(p, p->x, x, (size_t)p->m * 3); return EGS_OK; });
+}
+
+egs_status egs_problem_get_accumulators(egs_problem *p, double *a) {
+  if (!p || !a) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status { download_real(p, p->acc, a, (size_t)p->n * 6); return EGS_OK; });
+}
+
+egs_status egs_problem_set_state(egs_problem *p, const double *pos, const double *R, const double *v,
+                                 const double *w, const double *Minv, const double *f_ext) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    const size_t n = p->n;
+    hipStream_t s = p->ctx->stream;
+    if (pos) upload(p->pos, pos, n * 3, s);
+    if (R) upload(p->R, R, n * 9, s);
+    if (v) upload(p->v, v, n * 3, s);
+    if (w) upload(p->w, w, n * 3, s);
+    if (Minv) { upload(p->Minv_d, Minv, n * 36, s); p->minv_r_valid = false; }
+    if (f_ext) upload(p->f_ext, f_ext, n * 6, s);
+    p->have_state = true;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind, const double *data) {
+  if (!p) return EGS_ERR_INVALID;
+  if (p->m > 0 && (!kind || !data)) return fail(p->ctx, EGS_ERR_INVALID, "NULL constraint descriptors");
+  for (int i = 0; i < p->m; ++i)
+    if (kind[i] != EGS_JOINT_BALL && kind[i] != EGS_CONTACT_BOX)
+      return fail(p->ctx, EGS_ERR_INVALID, "unknown constraint kind");
+  for (int i = 0; i < p->m; ++i)
+    if (kind[i] == EGS_JOINT_BALL && p->plan.m == p->m) {
+      // a joint always has body0 (joints.h:16-22)
+    }
+  return guarded(p->ctx, [&]() -> egs_status {
+    upload(p->kind, kind, (size_t)p->m, p->ctx->stream);
+    upload(p->data, data, (size_t)p->m * 7, p->ctx->stream);
+    p->have_constraints = true;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_assemble(egs_problem *p, double dt, double erp) {
+  if (!p) return EGS_ERR_INVALID;
+  if (!p->have_state || !p->have_constraints) return fail(p->ctx, EGS_ERR_INVALID, "set_state and set_constraints first");
+  if (!(dt > 0)) return fail(p->ctx, EGS_ERR_INVALID, "dt must be > 0");
+  return guarded(p->ctx, [&]() -> egs_status { do_assemble(p, dt, erp); return EGS_OK; });
+}
+
+egs_status egs_problem_step(egs_problem *p, double dt, double erp, const egs_solve_params *params,
+                            egs_solve_stats *stats) {
+  if (!p) return EGS_ERR_INVALID;
+  if (!p->have_state || !p->have_constraints) return fail(p->ctx, EGS_ERR_INVALID, "set_state and set_constraints first");
+  if (!(dt > 0)) return fail(p->ctx, EGS_ERR_INVALID, "dt must be > 0");
+  return guarded(p->ctx, [&]() -> egs_status {
+    do_assemble(p, dt, erp);
+    egs_status st = do_solve(p, params, stats);
+    if (st != EGS_OK) return st;
+    do_velocity(p, dt);
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_get_blocks(egs_problem *p, double *J0, double *J1, uint8_t *is_eq, double *lo,
+                                  double *hi, double *rhs, double *err) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    const size_t m = p->m;
+    download_real(p, p->J0, J0, m * 18);
+    download_real(p, p->J1, J1, m * 18);
+    download_real(p, p->lo, lo, m * 3);
+    download_real(p, p->hi, hi, m * 3);
+    download_real(p, p->rhs, rhs, m * 3);
+    hipStream_t s = p->ctx->stream;
+    if (is_eq && m) HIPCHK(hipMemcpyAsync(is_eq, p->is_eq.p, m * 3, hipMemcpyDeviceToHost, s));
+    if (err && m) HIPCHK(hipMemcpyAsync(err, p->err.p, m * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_get_velocity(egs_problem *p, double *v6) {
+  if (!p || !v6) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    if (p->n) HIPCHK(hipMemcpyAsync(v6, p->v6.p, (size_t)p->n * 6 * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats) {
+  if (!p || !stats) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    std::memset(stats, 0, sizeof *stats);
+    fill_stats(p, stats);
+    stats->iterations = p->last_iterations;
+    if (p->m == 0) return EGS_OK;
+    int flag = 0;
+    stats->residual = read_residual(p, &flag);
+    stats->status = flag ? EGS_ERR_STALL : EGS_OK;
+    return flag ? fail(p->ctx, EGS_ERR_STALL, "device ordering wait timed out") : EGS_OK;
+  });
+}
+
+egs_status egs_solve_blocks(egs_context *ctx, int32_t n, const double *Minv, int32_t m, const int32_t *body0,
+                            const int32_t *body1, const double *J0, const double *J1, const uint8_t *is_eq,
+                            const double *lo, const double *hi, const double *rhs, const egs_solve_params *params,
+                            int32_t precision, double *x, egs_solve_stats *stats) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (m > 0 && (!Minv || !J0 || !J1 || !is_eq || !lo || !hi || !rhs || !x))
+    return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  egs_problem *p = nullptr;
+  egs_status st = egs_problem_create(ctx, n, m, body0, body1, precision, &p);
+  if (st != EGS_OK) return st;
+  st = egs_problem_set_blocks(p, Minv, J0, J1, is_eq, lo, hi, rhs);
+  egs_solve_stats local;
+  if (st == EGS_OK) st = egs_problem_solve(p, params, stats ? stats : &local);
+  if (st == EGS_OK && m > 0) st = egs_problem_get_lambda(p, x);
+  egs_problem_destroy(p);
+  return st;
+}
+
+egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double *A, const double *b,
+                                       const uint8_t *C, const double *lo, const double *hi, int32_t use_bounds,
+                                       double *x, double *w, int32_t *ok, int32_t *pivots) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (N < 0 || (N > 0 && (!A || !b || !C || !lo || !hi || !x || !w))) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  (void)use_bounds; (void)ok; (void)pivots;
+  return fail(ctx, EGS_ERR_UNSUPPORTED, "dense LCP (entry 3) is not built yet");
+}
+
+}  // extern "C"

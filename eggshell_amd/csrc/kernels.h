@@ -1,0 +1,82 @@
+// kernels.h -- launch interface between the C-ABI layer and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace egs {
+
+// Flat system + tile plan, all device pointers.
+template <typename REAL>
+struct SolveArgs {
+  const LaneDesc *lanes;
+  const int32_t *tile_nslots;
+  const int32_t *tile_slot_off;
+  const int32_t *slot_body;
+  const REAL *Minv;            // [n][36]
+  const REAL *J0, *J1;         // [m][18]
+  const uint8_t *is_eq;        // [3m]
+  const REAL *lo, *hi, *rhs;   // [3m]
+  REAL *x;                     // [3m]  in (resume) / out
+  REAL *acc;                   // [n][6] in (resume) / out
+  REAL *wres;                  // [3m]  out: A x - rhs
+  int32_t *error_flag;
+  REAL cfm, kscale;
+  int32_t sweeps, resume, max_slots;
+  uint32_t spin_limit;
+};
+
+template <typename REAL>
+struct GlobalArgs {
+  const GlobalDesc *cons;      // [mg]
+  int32_t mg, per_lane;        // constraints, constraints per lane
+  int32_t n_bodies, pad0;
+  const REAL *Minv, *J0, *J1;
+  const uint8_t *is_eq;
+  const REAL *lo, *hi, *rhs;
+  REAL *x, *acc, *wres;
+  REAL *B0, *B1, *D, *den, *dx; // workspace [mg][18|18|9|3|3]
+  uint32_t *tickets;           // [n] zeroed before every launch
+  int32_t *error_flag;
+  REAL cfm, kscale;
+  int32_t sweeps, resume, method;
+  int32_t mode;                // 0 = full sweeps, 1 = ordered accumulate of dx only
+  uint32_t spin_limit;
+};
+
+struct AssembleArgs {
+  int32_t n, m;
+  const double *pos, *R, *v, *w, *Minv, *f_ext;  // body state, fp64
+  const int32_t *kind, *body0, *body1;
+  const double *data;                            // [m][7]
+  double dt, erp;
+  void *J0, *J1, *lo, *hi, *rhs;                 // REAL outputs
+  double *err;                                   // [3m] fp64
+  uint8_t *is_eq;
+};
+
+template <typename REAL>
+void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
+                       int block, hipStream_t s);
+template <typename REAL>
+void launch_global_solve(const GlobalArgs<REAL> &a, hipStream_t s);
+template <typename REAL>
+void launch_assemble(const AssembleArgs &a, hipStream_t s);
+// partial sums of squares by row category: out[4*blocks]
+template <typename REAL>
+void launch_residual_partials(int rows, const REAL *wres, const REAL *x,
+                              const REAL *lo, const REAL *hi,
+                              const uint8_t *is_eq, double *out, int blocks,
+                              hipStream_t s);
+template <typename REAL>
+void launch_velocity(int n, const double *v, const double *w,
+                     const double *Minv, const double *f_ext, const REAL *acc,
+                     double dt, double *v6, hipStream_t s);
+template <typename REAL>
+void launch_convert_minv(int count, const double *src, REAL *dst, hipStream_t s);
+
+constexpr int kResidualBlocks = 64;
+
+}  // namespace egs

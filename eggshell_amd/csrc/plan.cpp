@@ -1,0 +1,155 @@
+// plan.cpp -- islands, tiles and per-body tickets (see plan.h).
+#include "plan.h"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+
+namespace egs {
+
+namespace {
+struct UnionFind {
+  std::vector<int32_t> parent;
+  explicit UnionFind(int n) : parent(n) { std::iota(parent.begin(), parent.end(), 0); }
+  int find(int a) {
+    while (parent[a] != a) {
+      parent[a] = parent[parent[a]];
+      a = parent[a];
+    }
+    return a;
+  }
+  void unite(int a, int b) {
+    a = find(a); b = find(b);
+    if (a != b) parent[std::max(a, b)] = std::min(a, b);
+  }
+};
+}  // namespace
+
+Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
+                int block) {
+  if (n_bodies < 0 || m < 0 || block <= 0 || block > 1024)
+    throw std::invalid_argument("build_plan: bad sizes");
+  Plan plan;
+  plan.n = n_bodies; plan.m = m; plan.block = block;
+  for (int i = 0; i < m; ++i) {
+    if (body0[i] < -1 || body0[i] >= n_bodies || body1[i] < -1 || body1[i] >= n_bodies)
+      throw std::invalid_argument("build_plan: body index out of range");
+  }
+
+  // 1. islands: union bodies that share a constraint.
+  UnionFind uf(n_bodies);
+  for (int i = 0; i < m; ++i)
+    if (body0[i] >= 0 && body1[i] >= 0) uf.unite(body0[i], body1[i]);
+
+  // island id per constraint, numbered by first appearance in list order.
+  // A constraint with both sides = world is an island of its own.
+  std::vector<int32_t> root_island(n_bodies, -1), cons_island(m);
+  std::vector<int32_t> island_size;
+  for (int i = 0; i < m; ++i) {
+    const int b = body0[i] >= 0 ? body0[i] : body1[i];
+    int isl;
+    if (b < 0) {
+      isl = (int)island_size.size();
+      island_size.push_back(0);
+    } else {
+      const int r = uf.find(b);
+      if (root_island[r] < 0) {
+        root_island[r] = (int)island_size.size();
+        island_size.push_back(0);
+      }
+      isl = root_island[r];
+    }
+    cons_island[i] = isl;
+    ++island_size[isl];
+  }
+  plan.n_islands = (int)island_size.size();
+
+  // 2. per-body rank (pos) and count (cnt) in list order.
+  std::vector<int32_t> cnt(n_bodies, 0), pos0(m, 0), pos1(m, 0);
+  for (int i = 0; i < m; ++i) {
+    if (body0[i] >= 0) pos0[i] = cnt[body0[i]]++;
+    if (body1[i] >= 0 && body1[i] != body0[i]) pos1[i] = cnt[body1[i]]++;
+    else if (body1[i] >= 0) pos1[i] = pos0[i];  // same body on both sides
+  }
+
+  // 3. pack whole islands into tiles, first-fit in island order; islands that
+  //    exceed a tile (or whose per-body count overflows 16 bits) go global.
+  std::vector<int32_t> island_tile(plan.n_islands, -1);
+  std::vector<int32_t> tile_fill;
+  {
+    int cur = -1;
+    for (int isl = 0; isl < plan.n_islands; ++isl) {
+      if (island_size[isl] > block) { island_tile[isl] = -2; continue; }
+      if (cur < 0 || tile_fill[cur] + island_size[isl] > block) {
+        cur = (int)tile_fill.size();
+        tile_fill.push_back(0);
+      }
+      island_tile[isl] = cur;
+      tile_fill[cur] += island_size[isl];
+    }
+  }
+  plan.n_tiles = (int)tile_fill.size();
+
+  // lane order inside a tile: by (island, list index) so that one island's
+  // constraints sit in as few wavefronts as possible.
+  std::vector<int32_t> order(m);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return cons_island[a] < cons_island[b];
+  });
+
+  LaneDesc idle{};
+  idle.cidx = -1;
+  plan.lanes.assign((size_t)plan.n_tiles * block, idle);
+  plan.tile_nslots.assign(plan.n_tiles, 1);
+  plan.tile_slot_off.assign(plan.n_tiles, 0);
+  std::vector<int32_t> lane_fill(plan.n_tiles, 0);
+  std::vector<int32_t> body_slot(n_bodies, -1);
+  std::vector<std::vector<int32_t>> tile_bodies(plan.n_tiles);
+
+  auto slot_of = [&](int tile, int body) -> uint16_t {
+    if (body < 0) return 0;
+    if (body_slot[body] < 0) {
+      body_slot[body] = plan.tile_nslots[tile]++;
+      tile_bodies[tile].push_back(body);
+    }
+    return (uint16_t)body_slot[body];
+  };
+
+  for (int k = 0; k < m; ++k) {
+    const int i = order[k];
+    const int tile = island_tile[cons_island[i]];
+    if (tile == -2) continue;
+    LaneDesc d;
+    d.cidx = i;
+    d.slot0 = slot_of(tile, body0[i]);
+    d.slot1 = slot_of(tile, body1[i]);
+    d.pos0 = (uint16_t)pos0[i];
+    d.cnt0 = (uint16_t)(body0[i] >= 0 ? cnt[body0[i]] : 0);
+    d.pos1 = (uint16_t)pos1[i];
+    d.cnt1 = (uint16_t)(body1[i] >= 0 ? cnt[body1[i]] : 0);
+    plan.lanes[(size_t)tile * block + lane_fill[tile]++] = d;
+  }
+  int off = 0;
+  for (int t = 0; t < plan.n_tiles; ++t) {
+    plan.tile_slot_off[t] = off;
+    plan.slot_body.push_back(-1);
+    for (int b : tile_bodies[t]) plan.slot_body.push_back(b);
+    off += plan.tile_nslots[t];
+    plan.max_slots = std::max(plan.max_slots, plan.tile_nslots[t]);
+  }
+
+  // 4. oversize islands, in list order.
+  for (int i = 0; i < m; ++i) {
+    if (island_tile[cons_island[i]] != -2) continue;
+    GlobalDesc g{};
+    g.cidx = i;
+    g.body0 = body0[i]; g.body1 = body1[i];
+    g.pos0 = pos0[i]; g.cnt0 = body0[i] >= 0 ? cnt[body0[i]] : 0;
+    g.pos1 = pos1[i]; g.cnt1 = body1[i] >= 0 ? cnt[body1[i]] : 0;
+    plan.global.push_back(g);
+  }
+  return plan;
+}
+
+}  // namespace egs

@@ -1,0 +1,50 @@
+// plan.h -- host-side analysis of the constraint graph.
+//
+// The reference sweeps the ConstraintsList strictly in list order
+// (sparse_iterations_utils.cc:159-243 forward, :292-373 backward).  Two
+// constraints interact only through a shared body, so the sweep is a partial
+// order: per body, its constraints must run in list order.  The plan
+//   1. finds the connected components ("islands") of the constraint graph,
+//   2. packs whole islands into workgroup-sized tiles (one workgroup owns all
+//      constraints of every body it touches, so body accumulators live in LDS),
+//   3. numbers, for every constraint side, its rank among the constraints of
+//      that body (`pos`) and the body's constraint count (`cnt`): the device
+//      code uses them as tickets to reproduce list order exactly,
+//   4. routes islands larger than a tile to the cross-workgroup path.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace egs {
+
+struct LaneDesc {      // one per lane of a tile; 16 bytes
+  int32_t cidx;        // constraint index in the caller's list, -1 = idle lane
+  uint16_t slot0;      // LDS slot of body0 (0 = world / none)
+  uint16_t slot1;
+  uint16_t pos0, cnt0; // rank of this constraint among body0's, and their count
+  uint16_t pos1, cnt1;
+};
+
+struct GlobalDesc {    // one per constraint of the cross-workgroup path; 24 bytes
+  int32_t cidx;
+  int32_t body0, body1;
+  int32_t pos0, cnt0;
+  int32_t pos1, cnt1;
+  int32_t pad;
+};
+
+struct Plan {
+  int n = 0, m = 0, block = 256;
+  int n_islands = 0, n_tiles = 0, max_slots = 1;
+  std::vector<LaneDesc> lanes;        // n_tiles * block
+  std::vector<int32_t> tile_nslots;   // per tile, slots in use (slot 0 = world)
+  std::vector<int32_t> tile_slot_off; // per tile, offset into slot_body
+  std::vector<int32_t> slot_body;     // slot -> global body index (-1 for slot 0)
+  std::vector<GlobalDesc> global;     // constraints of oversize islands, list order
+};
+
+// Throws std::invalid_argument on out-of-range body indices.
+Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
+                int block);
+
+}  // namespace egs

@@ -1,0 +1,180 @@
+/*
+ * eggshell_amd.h -- C ABI of the MI355X (gfx950) constraint-solve library,
+ * libeggshell_amd.so.  Plain pointers and sizes only; all arrays are host
+ * memory, row-major, IEEE fp64 unless stated; the library owns device memory.
+ *
+ * It is a drop-in for ONE path of teenylasers/eggshell: the per-step
+ * constraint solve.  Each entry point names the reference interface it
+ * replaces (file:line relative to the reference tree).
+ *
+ * Conventions (as in the reference):
+ *   - a body has 6 velocity coordinates [v_lin; omega] (ensembles.cc:429-436);
+ *   - every constraint has exactly 3 rows (joints.cc:18-19, contact.cc:103);
+ *   - body index -1 is the world (constraints.h:42-43);
+ *   - rows are ordered as the ConstraintsList is (ensembles.cc:234-239);
+ *   - is_eq[r] != 0 marks an equality row ("C" in the reference); inequality
+ *     rows are clamped to [lo, hi], +-inf allowed
+ *     (sparse_iterations_utils.cc:12-21).
+ *
+ * Error convention: every function returns an egs_status; nothing ever exits
+ * the process (the reference Panics: toolkit/error.cc:92-100).  The message
+ * for the last failure is egs_last_error().  Non-convergence of the iterative
+ * solver is NOT an error, exactly as in the reference
+ * (sparse_iterations.cc:208-225 returns the last iterate silently).
+ */
+#ifndef EGGSHELL_AMD_H
+#define EGGSHELL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct egs_context egs_context; /* one per (process, GPU): device + stream */
+typedef struct egs_problem egs_problem; /* one ensemble (or batch) resident on the GPU */
+
+typedef enum {
+  EGS_OK = 0,
+  EGS_ERR_INVALID = 1,     /* bad argument (the reference would CHECK/Panic) */
+  EGS_ERR_NO_DEVICE = 2,   /* no gfx950 device / HIP runtime unusable */
+  EGS_ERR_HIP = 3,         /* a HIP call failed */
+  EGS_ERR_STALL = 4,       /* device-side ordering wait timed out (bug guard) */
+  EGS_ERR_UNSUPPORTED = 5, /* feature not built yet */
+  EGS_ERR_LCP_FAILED = 6   /* dense LCP did not reach a solution (lcp.cc:250) */
+} egs_status;
+
+/* sparse_iterations.cc:21-26 */
+typedef enum { EGS_JACOBI = 0, EGS_GAUSS_SEIDEL = 1, EGS_SOR = 2 } egs_method;
+typedef enum { EGS_F64 = 0, EGS_F32 = 1 } egs_precision;
+/* constraint descriptor kinds for device-side assembly */
+typedef enum { EGS_JOINT_BALL = 0, EGS_CONTACT_BOX = 1 } egs_constraint_kind;
+
+/* Runtime form of the reference's compile-time constants:
+ *   omega = 1.5 and max_iters = 500 (sparse_iterations.cc:15-19),
+ *   tol = kAllowNumericalError = 1e-9 (constants.h:5),
+ *   cfm = the `cfm` argument of sparse::*Iteration (sparse_iterations.h:26-34).
+ * tol <= 0 runs exactly max_iters sweeps (the benchmark mode).
+ * check_every = k evaluates the residual every k sweeps; k = 1 reproduces the
+ * reference's stopping rule exactly. */
+typedef struct {
+  int32_t method;      /* egs_method */
+  int32_t max_iters;
+  int32_t check_every;
+  int32_t reserved;
+  double omega;
+  double cfm;
+  double tol;
+} egs_solve_params;
+
+typedef struct {
+  int32_t iterations;  /* sweeps performed */
+  int32_t status;      /* egs_status of the device run */
+  double residual;     /* sparse_iterations.cc:51-69 metric of the returned x */
+  int32_t n_islands;   /* connected components of the constraint graph */
+  int32_t n_tiles;     /* workgroup-resident tiles */
+  int32_t n_global;    /* constraints solved by the cross-workgroup path */
+  int32_t reserved;
+} egs_solve_stats;
+
+void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */
+
+/* ---- context ------------------------------------------------------------ */
+egs_status egs_context_create(int device_index, egs_context **out);
+void egs_context_destroy(egs_context *ctx);
+const char *egs_last_error(const egs_context *ctx);
+egs_status egs_context_synchronize(egs_context *ctx);
+/* hipEvent pair on the context's stream (the stream every kernel below is
+ * launched on).  stop() synchronises and returns elapsed milliseconds. */
+egs_status egs_timer_start(egs_context *ctx);
+egs_status egs_timer_stop(egs_context *ctx, float *elapsed_ms);
+/* Sum and count of the solve-kernel launch durations (hipEvents around each
+ * launch) since the last reset; synchronises. */
+egs_status egs_kernel_time(egs_context *ctx, double *sum_ms, int64_t *launches,
+                           int reset);
+
+/* ---- entry 1: replaces sparse::{Jacobi,GaussSeidel,SOR}Iteration
+ *      (const ConstraintsList&, const MatrixXd& M_inverse, const VectorXd& rhs,
+ *       double cfm)   sparse_iterations.h:26-34 / sparse_iterations.cc:148-286.
+ * The C++ adapter flattens the ConstraintsList with m ComputeJ calls:
+ *   Minv  [n][36]  the 6x6 diagonal blocks M_inverse.block<6,6>(6b,6b)
+ *   body0/1 [m]    Constraint::i0_, i1_ (constraints.h:42-43)
+ *   J0,J1 [m][18]  the 3x6 blocks ComputeJ returns (constraints.h:22-24)
+ *   is_eq, lo, hi [3m], rhs [3m];  out x [3m].
+ * x0 = rhs, stop at residual <= tol or max_iters sweeps.                     */
+egs_status egs_solve_blocks(egs_context *ctx, int32_t n_bodies,
+                            const double *Minv, int32_t m,
+                            const int32_t *body0, const int32_t *body1,
+                            const double *J0, const double *J1,
+                            const uint8_t *is_eq, const double *lo,
+                            const double *hi, const double *rhs,
+                            const egs_solve_params *params, int32_t precision,
+                            double *x, egs_solve_stats *stats);
+
+/* ---- device-resident form of the same path (what bench.py times) -------- */
+/* Analyses the constraint graph (islands -> workgroup tiles) and allocates
+ * device storage.  The topology (body0/body1) is fixed for the problem's life;
+ * values can be re-uploaded any number of times. */
+egs_status egs_problem_create(egs_context *ctx, int32_t n_bodies, int32_t m,
+                              const int32_t *body0, const int32_t *body1,
+                              int32_t precision, egs_problem **out);
+void egs_problem_destroy(egs_problem *p);
+/* upload the flat system of entry 1 (any pointer may be NULL = keep) */
+egs_status egs_problem_set_blocks(egs_problem *p, const double *Minv,
+                                  const double *J0, const double *J1,
+                                  const uint8_t *is_eq, const double *lo,
+                                  const double *hi, const double *rhs);
+/* asynchronous on the context stream */
+egs_status egs_problem_solve(egs_problem *p, const egs_solve_params *params,
+                             egs_solve_stats *stats);
+egs_status egs_problem_get_lambda(egs_problem *p, double *x /*[3m]*/);
+/* a_b = Minv_b sum_i J_ib^T lambda_i, [n][6]: the solver's by-product,
+ * so that v_dot = Minv f_ext + a (ensembles.cc:535) needs no extra pass. */
+egs_status egs_problem_get_accumulators(egs_problem *p, double *a /*[n][6]*/);
+
+/* ---- entry 2: replaces the assembly half of Ensemble::StepVelocities_ODE
+ *      (ensembles.cc:563-575): ComputeJ (ensembles.cc:38-87 ->
+ *      joints.cc:13-35, contact.cc:38-117), ComputePositionConstraintError
+ *      (ensembles.cc:156-171 -> joints.cc:3-11, contact.cc:14-22), the rhs
+ *      (ensembles.cc:569-570) and, after the solve, the velocity update
+ *      (ensembles.cc:535, 572).  Body state and constraint descriptors:
+ *   pos [n][3], R [n][9] row-major, v [n][3], w [n][3] (global frame),
+ *   Minv [n][36], f_ext [n][6]  (ensembles.cc:202-222; frozen at Init, Q5)
+ *   kind [m] (egs_constraint_kind),
+ *   data [m][7]: joint   = c0(3), c1(3) (c1 = world point if body1 = -1), 0
+ *                contact = position(3), normal(3), depth (collision.h:12-27) */
+egs_status egs_problem_set_state(egs_problem *p, const double *pos,
+                                 const double *R, const double *v,
+                                 const double *w, const double *Minv,
+                                 const double *f_ext);
+egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind,
+                                       const double *data);
+/* J, err, bounds, rhs = -(erp/dt^2) err - J (v/dt + Minv f_ext) on device */
+egs_status egs_problem_assemble(egs_problem *p, double dt, double erp);
+/* assemble + solve + v_new = v + dt (Minv f_ext + a): one whole hot-path pass */
+egs_status egs_problem_step(egs_problem *p, double dt, double erp,
+                            const egs_solve_params *params,
+                            egs_solve_stats *stats);
+egs_status egs_problem_get_blocks(egs_problem *p, double *J0, double *J1,
+                                  uint8_t *is_eq, double *lo, double *hi,
+                                  double *rhs, double *err);
+egs_status egs_problem_get_velocity(egs_problem *p, double *v6 /*[n][6]*/);
+/* fills stats->residual/iterations of the last solve (synchronises) */
+egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats);
+
+/* ---- entry 3: replaces Lcp::MixedConstraintsSolver(A, b, C, x_lo, x_hi, x, w)
+ *      lcp.h:21-23 / lcp.cc:276-336 (and Lcp::MurtyPrincipalPivot,
+ *      lcp.cc:157-274).  A [N][N], b, C, lo, hi [N] -> x, w [N]; *ok as the
+ *      reference's bool.  use_bounds = 0 reproduces the reference (bounds
+ *      ignored, quirk Q3); 1 solves the true box problem.                    */
+egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N,
+                                       const double *A, const double *b,
+                                       const uint8_t *C, const double *lo,
+                                       const double *hi, int32_t use_bounds,
+                                       double *x, double *w, int32_t *ok,
+                                       int32_t *pivots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
