@@ -24,7 +24,7 @@ EXPORTS = [
     "egs_problem_solve", "egs_problem_get_lambda", "egs_problem_get_accumulators",
     "egs_problem_set_state", "egs_problem_set_constraints", "egs_problem_assemble",
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
-    "egs_problem_get_stats", "egs_mixed_constraints_solve",
+    "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
 ]
 
 
@@ -220,3 +220,17 @@ class Problem:
         self.ctx.check(load().egs_problem_get_blocks(self.h, _p(J0), _p(J1), _p(is_eq), _p(lo), _p(hi),
                                                      _p(rhs), _p(err)))
         return J0, J1, is_eq, lo, hi, rhs, err
+
+
+def debug_plan(n_bodies, body0, body1, tile_size=256):
+    """Host-only view of the schedule (islands, tiles, tickets); needs no GPU."""
+    body0, body1 = _i32(body0), _i32(body1)
+    m = body0.shape[0]
+    ni, nt, ng = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    out = [np.zeros(m, np.int32) for _ in range(5)]
+    st = load().egs_debug_plan(C.c_int32(n_bodies), C.c_int32(m), _p(body0), _p(body1), C.c_int32(tile_size),
+                               C.byref(ni), C.byref(nt), C.byref(ng), *[_p(o) for o in out])
+    if st != OK:
+        raise EgsError(st, "egs_debug_plan failed")
+    return dict(n_islands=ni.value, n_tiles=nt.value, n_global=ng.value, cons_tile=out[0],
+                pos0=out[1], cnt0=out[2], pos1=out[3], cnt1=out[4])

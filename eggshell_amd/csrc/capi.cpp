@@ -658,4 +658,38 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
   return fail(ctx, EGS_ERR_UNSUPPORTED, "dense LCP (entry 3) is not built yet");
 }
 
+egs_status egs_debug_plan(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,
+                          int32_t *n_islands, int32_t *n_tiles, int32_t *n_global, int32_t *cons_tile,
+                          int32_t *pos0, int32_t *cnt0, int32_t *pos1, int32_t *cnt1) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
+  try {
+    const Plan pl = build_plan(n, m, body0, body1, tile_size);
+    if (n_islands) *n_islands = pl.n_islands;
+    if (n_tiles) *n_tiles = pl.n_tiles;
+    if (n_global) *n_global = (int32_t)pl.global.size();
+    for (int i = 0; i < m; ++i) {
+      if (cons_tile) cons_tile[i] = -1;
+    }
+    for (int t = 0; t < pl.n_tiles; ++t)
+      for (int l = 0; l < pl.block; ++l) {
+        const LaneDesc &d = pl.lanes[(size_t)t * pl.block + l];
+        if (d.cidx < 0) continue;
+        if (cons_tile) cons_tile[d.cidx] = t;
+        if (pos0) pos0[d.cidx] = d.pos0;
+        if (cnt0) cnt0[d.cidx] = d.cnt0;
+        if (pos1) pos1[d.cidx] = d.pos1;
+        if (cnt1) cnt1[d.cidx] = d.cnt1;
+      }
+    for (const GlobalDesc &g : pl.global) {
+      if (pos0) pos0[g.cidx] = g.pos0;
+      if (cnt0) cnt0[g.cidx] = g.cnt0;
+      if (pos1) pos1[g.cidx] = g.pos1;
+      if (cnt1) cnt1[g.cidx] = g.cnt1;
+    }
+    return EGS_OK;
+  } catch (const std::exception &) {
+    return EGS_ERR_INVALID;
+  }
+}
+
 }  // extern "C"

@@ -174,6 +174,19 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N,
                                        double *x, double *w, int32_t *ok,
                                        int32_t *pivots);
 
+/* ---- diagnostics (host only, needs no GPU) -------------------------------
+ * The schedule the solver derives from the constraint graph: islands, the
+ * workgroup tile each constraint lands in (-1 = cross-workgroup path) and the
+ * per-body tickets (rank/count of the constraint among its body's, list
+ * order) that make the parallel sweep reproduce the reference's list order
+ * (sparse_iterations_utils.cc:159-243, 292-373).  Arrays [m], may be NULL.   */
+egs_status egs_debug_plan(int32_t n_bodies, int32_t m, const int32_t *body0,
+                          const int32_t *body1, int32_t tile_size,
+                          int32_t *n_islands, int32_t *n_tiles,
+                          int32_t *n_global, int32_t *cons_tile,
+                          int32_t *pos0, int32_t *cnt0, int32_t *pos1,
+                          int32_t *cnt1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,8 +137,13 @@ static int murty_impl(int dim, const double *A, const double *b,
     S[i] = 1; x[i] = 0; w[i] = -b[i]; C[i] = lo[i]; /* :176-189 */
     bx[i] = x[i]; bw[i] = w[i];
   }
+  /* box_fix only: the reference's start (x = 0, w = -b) passes its own check
+   * whenever lo < 0 < hi ("WithBound solutions are trivial", lcp.cc:181), so
+   * the corrected variant solves once for S = all before the first check. */
+  int force = box_fix;
   while (iter < max_iterations) {
-    if (!orc_check_murty(dim, A, b, x, w, S, C, lo, hi, 0)) {
+    if (force || !orc_check_murty(dim, A, b, x, w, S, C, lo, hi, 0)) {
+      force = 0;
       int ns = 0;
       for (int i = 0; i < dim; ++i) if (S[i]) idx[ns++] = i;
       /* x(!S) first (values do not depend on the solve) :208-216 */
@@ -174,8 +179,10 @@ static int murty_impl(int dim, const double *A, const double *b,
     }
     ++iter;
   }
-  memcpy(x, bx, sizeof(double) * dim); /* :241-242 */
-  memcpy(w, bw, sizeof(double) * dim);
+  if (!box_fix) { /* the "goodness" ranking assumes lo = 0; box_fix keeps the last iterate */
+    memcpy(x, bx, sizeof(double) * dim); /* :241-242 */
+    memcpy(w, bw, sizeof(double) * dim);
+  }
   int ok = orc_check_murty(dim, A, b, x, w, S, C, lo, hi,
                            iter >= max_iterations ? 1e-8 : 0); /* :244-249 */
   if (pivots_out) *pivots_out = pivots;

@@ -76,3 +76,60 @@ def check_mixed_solution(A, b, x, is_eq, lo, hi, tol=1e-9):
         else:
             return False
     return True
+
+
+def ode_step(sc, dt, erp=0.2):
+    """One Ensemble::Step(dt, OPEN_DYNAMICS_ENGINE) of a contact-free ensemble
+    through the reference's LIVE dense path (ensembles.cc:390-427, 498-538,
+    563-591), built from oracle pieces.  M^-1 and f_ext are frozen at Init
+    (quirk Q5): pass them in sc['Minv0'], sc['f_ext0'] (created on first use)."""
+    if "Minv0" not in sc:
+        sc["Minv0"] = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        sc["f_ext0"] = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+    J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+    s = orc.Sys(sc["Minv0"], sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+    rhs = orc.ode_rhs(sc["v"], sc["w"], s.Minv, sc["f_ext0"], s.body0, s.body1, J0, J1, err, dt, erp)
+    A = orc.dense_JMJt(s, 0.0)
+    if not np.linalg.cond(A) < 1e7:           # ensembles.cc:513-521
+        A = A + 0.01 * np.eye(A.shape[0])
+    ok, lam, w, _ = orc.mixed_constraints(A, rhs, is_eq, lo, hi)
+    assert ok
+    v6 = orc.velocity_update(sc["v"], sc["w"], s.Minv, sc["f_ext0"], s.body0, s.body1, J0, J1, lam, dt)
+    v6_old = np.concatenate([sc["v"], sc["w"]], axis=1)
+    p, R = orc.position_update(sc["p"], sc["R"], v6_old, v6, dt)
+    sc["p"], sc["R"] = p, R
+    sc["v"], sc["w"] = v6[:, 0:3].copy(), v6[:, 3:6].copy()
+    return lam
+
+
+def random_system(rng, n, m, world_frac=0.2, eq_frac=0.4, connected=False):
+    """A random flat system: random topology, random J blocks, SPD 6x6 M^-1
+    blocks, mixed equality / box rows (some infinite bounds)."""
+    body0 = np.zeros(m, np.int32); body1 = np.zeros(m, np.int32)
+    for i in range(m):
+        if connected and i < n - 1:
+            a, b = i, i + 1
+        else:
+            a = int(rng.integers(0, n)); b = int(rng.integers(0, n - 1))
+            if b >= a:
+                b += 1
+        r = rng.uniform()
+        if r < world_frac / 2:
+            a = -1
+        elif r < world_frac:
+            b = -1
+        body0[i], body1[i] = a, b
+    J0 = rng.uniform(-1, 1, (m, 18)); J1 = rng.uniform(-1, 1, (m, 18))
+    J0[body0 < 0] = 0.0; J1[body1 < 0] = 0.0
+    Minv = np.zeros((n, 36))
+    for b in range(n):
+        M = rng.uniform(-1, 1, (6, 6))
+        Minv[b] = (M @ M.T + 0.5 * np.eye(6)).reshape(36)
+    is_eq = (rng.uniform(size=3 * m) < eq_frac).astype(np.uint8)
+    lo = -rng.uniform(0.1, 2.0, 3 * m); hi = rng.uniform(0.1, 2.0, 3 * m)
+    inf_hi = rng.uniform(size=3 * m) < 0.3
+    hi[inf_hi] = np.inf
+    lo[rng.uniform(size=3 * m) < 0.1] = -np.inf
+    lo[is_eq == 1] = 0.0; hi[is_eq == 1] = 0.0
+    rhs = rng.uniform(-1, 1, 3 * m)
+    return orc.Sys(Minv, body0, body1, J0, J1, is_eq, lo, hi), rhs

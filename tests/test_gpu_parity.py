@@ -1,0 +1,182 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle on
+the same inputs.  Bar: BIT-EXACT lambda and accumulators (the kernels perform
+the oracle's fma chains in the oracle's order; integer/index work exact);
+residuals, which are reduced in a different order, to 1e-12 relative."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from eggshell_amd import capi, scenes
+from helpers import random_system, system_from_scene
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+TAGS = ((0, "jacobi"), (1, "gs"), (2, "sor"))
+
+
+def gpu_solve(ctx, s, rhs, cfm, method, K, tol=0.0, precision=capi.F64, check_every=1):
+    pr = capi.Problem(ctx, s.n, s.body0, s.body1, precision)
+    pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+    st = pr.solve(capi.params(method=method, max_iters=K, tol=tol, cfm=cfm, check_every=check_every))
+    x, a = pr.lambda_(), pr.accumulators()
+    pr.close()
+    return x, a, st
+
+
+def same_bits(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixtures(ctx, path):
+    g = np.load(path)
+    s = orc.Sys(g["Minv"], g["body0"], g["body1"], g["J0"], g["J1"], g["is_eq"], g["lo"], g["hi"])
+    for method, tag in TAGS:
+        for K in (1, 10, 50):
+            x, a, st = gpu_solve(ctx, s, g["rhs"], float(g["cfm"]), method, K)
+            assert st.status == capi.OK and st.iterations == K
+            assert same_bits(x, g["x_%s_%d" % (tag, K)]), (tag, K)
+            assert same_bits(a, g["a_%s_%d" % (tag, K)]), (tag, K)
+            ref = float(g["res_%s_%d" % (tag, K)])
+            if np.isfinite(ref):
+                assert abs(st.residual - ref) <= 1e-12 * max(1.0, ref)
+
+
+@pytest.mark.parametrize("method", [capi.JACOBI, capi.GAUSS_SEIDEL, capi.SOR])
+def test_one_shot_entry_chain_and_stacks(ctx, method):
+    """egs_solve_blocks (the sparse::*Iteration replacement) on C1 and C2."""
+    rng = np.random.default_rng(10)
+    for sc, K in ((scenes.chain(8), 50), (scenes.box_stack(8, 8, 4), 50)):
+        s, _ = system_from_scene(sc)
+        rhs = rng.uniform(-1, 1, 3 * s.m)
+        x, st = ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs,
+                                 capi.params(method=method, max_iters=K, tol=0.0, cfm=0.01))
+        xf, a, it, rf = orc.fast_iterate(s, rhs, 0.01, method, max_iters=K, tol=0.0)
+        assert same_bits(x, xf)
+        assert st.n_global == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_topologies_bit_exact(ctx, seed):
+    """Fuzz the schedule: random graphs (world sides, shared bodies, several
+    islands per tile, islands in shuffled list order), mixed row types."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(3, 120))
+    m = int(rng.integers(1, 240))
+    s, rhs = random_system(rng, n, m, world_frac=float(rng.uniform(0, 0.5)))
+    for method in (capi.GAUSS_SEIDEL, capi.SOR, capi.JACOBI):
+        for K in (0, 1, 4, 23):
+            x, a, st = gpu_solve(ctx, s, rhs, 0.05, method, K)
+            xf, af, _, rf = orc.fast_iterate(s, rhs, 0.05, method, max_iters=K, tol=0.0)
+            assert st.status == capi.OK
+            assert same_bits(x, xf), (method, K)
+            assert same_bits(a, af), (method, K)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR, capi.JACOBI])
+def test_cross_workgroup_path_bit_exact(ctx, method):
+    """Islands larger than a workgroup tile: a 700-link chain (one island of
+    700 constraints) next to small islands, and a dense random island."""
+    rng = np.random.default_rng(7)
+    sc = scenes.concat([scenes.chain(700), scenes.box_stack(2, 2, 3), scenes.chain(5)])
+    s, _ = system_from_scene(sc)
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    for K in (0, 1, 6):
+        x, a, st = gpu_solve(ctx, s, rhs, 0.05, method, K)
+        assert st.status == capi.OK and st.n_global == 700
+        xf, af, _, _ = orc.fast_iterate(s, rhs, 0.05, method, max_iters=K, tol=0.0)
+        assert same_bits(x, xf) and same_bits(a, af), K
+    s2, rhs2 = random_system(rng, 60, 900, connected=True)
+    x, a, st = gpu_solve(ctx, s2, rhs2, 0.5, method, 3)
+    assert st.n_global == 900 and st.status == capi.OK
+    xf, af, _, _ = orc.fast_iterate(s2, rhs2, 0.5, method, max_iters=3, tol=0.0)
+    assert same_bits(x, xf) and same_bits(a, af)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR, capi.JACOBI])
+def test_reference_stopping_rule(ctx, method):
+    """tol = 1e-9, check_every = 1 (sparse_iterations.cc:206-222): same sweep
+    count and the same bits as the oracle; the result passes the reference's
+    CheckMixedConstraintSolutions (residual metric <= 1e-9)."""
+    rng = np.random.default_rng(11)
+    for sc in (scenes.chain(4), scenes.box_stack(2, 2, 2)):
+        s, _ = system_from_scene(sc)
+        if method == capi.JACOBI and sc["kind"][0] == 1:
+            continue   # Jacobi diverges on contacts (sparse_iterations.cc:576-578)
+        rhs = rng.uniform(-1, 1, 3 * s.m)
+        x, a, st = gpu_solve(ctx, s, rhs, 0.1, method, 500, tol=1e-9)
+        xf, af, it, rf = orc.fast_iterate(s, rhs, 0.1, method, max_iters=500, tol=1e-9)
+        assert st.iterations == it and it < 500
+        assert same_bits(x, xf)
+        assert st.residual <= 1e-9
+        assert orc.lit_residual(s, rhs, x, 0.1) <= 2e-9
+    # already converged at x0 = rhs: zero sweeps (rhs = 0)
+    s, _ = system_from_scene(scenes.chain(4))
+    x, a, st = gpu_solve(ctx, s, np.zeros(3 * s.m), 0.1, method, 500, tol=1e-9)
+    assert st.iterations == 0 and not x.any()
+
+
+def test_check_every_chunks(ctx):
+    """check_every = k stops at the first multiple of k that satisfies tol."""
+    rng = np.random.default_rng(12)
+    s, _ = system_from_scene(scenes.box_stack(2, 2, 3))
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    x, a, st = gpu_solve(ctx, s, rhs, 0.1, capi.GAUSS_SEIDEL, 500, tol=1e-9, check_every=7)
+    xf, af, it, rf = orc.fast_iterate(s, rhs, 0.1, orc.GAUSS_SEIDEL, max_iters=500, tol=1e-9, check_every=7)
+    assert st.iterations == it and it % 7 == 0
+    assert same_bits(x, xf) and same_bits(a, af)
+
+
+def test_fp32_mode(ctx):
+    """C4 precision: bit-exact against the fp32 oracle; against fp64 within the
+    stated tolerance 2e-3 relative (PGS 50 sweeps on a 4x4x4 stack)."""
+    rng = np.random.default_rng(13)
+    sc = scenes.box_stack(4, 4, 4, jitter=1e-3, seed=5)
+    s, _ = system_from_scene(sc)
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    for method in (capi.GAUSS_SEIDEL, capi.SOR):
+        x32, a32, st = gpu_solve(ctx, s, rhs, 0.01, method, 50, precision=capi.F32)
+        xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.01, method, max_iters=50)
+        assert same_bits(x32.astype(np.float32), xo)
+        assert same_bits(a32.astype(np.float32), ao)
+        x64, _, _, _ = orc.fast_iterate(s, rhs, 0.01, method, max_iters=50, tol=0.0)
+        assert np.abs(x32 - x64).max() <= 2e-3 * max(1.0, np.abs(x64).max())
+
+
+def test_empty_and_degenerate(ctx):
+    """m = 0 (sparse_iterations.cc:152-154); a single world-anchored joint; a
+    body no constraint touches."""
+    x, st = ctx.solve_blocks(np.zeros((3, 36)), [], [], np.zeros((0, 18)), np.zeros((0, 18)), [], [], [], [],
+                             capi.params(max_iters=5, tol=0.0))
+    assert x.shape == (0,) and st.iterations == 0
+    rng = np.random.default_rng(14)
+    s, rhs = random_system(rng, 3, 1, world_frac=1.0)
+    x, a, st = gpu_solve(ctx, s, rhs, 0.1, capi.GAUSS_SEIDEL, 5)
+    xf, af, _, _ = orc.fast_iterate(s, rhs, 0.1, orc.GAUSS_SEIDEL, max_iters=5, tol=0.0)
+    assert same_bits(x, xf) and same_bits(a, af)
+
+
+def test_invalid_arguments_do_not_crash(ctx):
+    """Precondition failures return EGS_ERR_INVALID (the reference Panics)."""
+    with pytest.raises(capi.EgsError) as e:
+        capi.Problem(ctx, 2, [0, 3], [1, 0])           # body index out of range
+    assert e.value.status == capi.ERR_INVALID
+    with pytest.raises(capi.EgsError) as e:
+        capi.Problem(ctx, 2, [1], [1])                 # same body on both sides
+    assert e.value.status == capi.ERR_INVALID
+    pr = capi.Problem(ctx, 2, [0], [1])
+    with pytest.raises(capi.EgsError) as e:
+        pr.solve(capi.params())                        # nothing uploaded
+    assert e.value.status == capi.ERR_INVALID
+    s, rhs = random_system(np.random.default_rng(1), 2, 1, world_frac=0.0)
+    pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+    with pytest.raises(capi.EgsError) as e:
+        pr.solve(capi.params(method=capi.SOR, omega=2.5))
+    assert e.value.status == capi.ERR_INVALID
+    with pytest.raises(capi.EgsError) as e:
+        pr.solve(capi.params(method=9))
+    assert e.value.status == capi.ERR_INVALID
+    pr.close()

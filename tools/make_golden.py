@@ -1,0 +1,80 @@
+"""Generate tests/golden/*.npz with the CPU oracle (run here, committed).
+
+Each fixture holds INPUTS (body state, constraint descriptors, flat system,
+rhs, solver parameters) and EXPECTED OUTPUTS (Jacobian blocks, A*x, lambda after
+K sweeps per method, residual, accumulators).  The reference itself holds no
+golden lambda/trajectory and cannot be built here (no Eigen), so
+these vectors come from the oracle, which tests/test_oracle_*.py pin against
+the reference's literal KATs, its property tests and an independent numpy
+dense implementation.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from eggshell_amd import scenes  # noqa: E402
+from helpers import ode_step, random_system  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SWEEPS = (1, 10, 50)
+
+
+def scene_fixture(name, sc, dt, cfm):
+    J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+    Minv = sc.get("Minv0")
+    if Minv is None:
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+    f_ext = sc.get("f_ext0")
+    if f_ext is None:
+        f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+    s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+    rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
+    d = dict(p=sc["p"], R=sc["R"], v=sc["v"], w=sc["w"], Minv=Minv, f_ext=f_ext, kind=sc["kind"],
+             body0=sc["body0"], body1=sc["body1"], data=sc["data"], dt=dt, erp=0.2, cfm=cfm,
+             J0=J0, J1=J1, is_eq=is_eq, lo=lo, hi=hi, err=err, rhs=rhs)
+    solve_outputs(d, s, rhs, cfm)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "n", s.n, "m", s.m)
+
+
+def solve_outputs(d, s, rhs, cfm):
+    d["Ax_rhs"] = orc.lit_JMJtX(s, rhs, cfm)
+    for method, tag in ((0, "jacobi"), (1, "gs"), (2, "sor")):
+        for K in SWEEPS:
+            x, a, it, res = orc.fast_iterate(s, rhs, cfm, method, max_iters=K, tol=0.0)
+            d["x_%s_%d" % (tag, K)] = x
+            d["a_%s_%d" % (tag, K)] = a
+            d["res_%s_%d" % (tag, K)] = res
+    if s.m <= 64:   # literal O(m^2) reference algorithm, same sweeps
+        for method, tag in ((0, "jacobi"), (1, "gs"), (2, "sor")):
+            x, it, res = orc.lit_iterate(s, rhs, cfm, method, max_iters=10, tol=0.0)
+            d["xlit_%s_10" % tag] = x
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    scene_fixture("chain4_t0", scenes.chain(4), 1e-3, 0.1)
+    sc = scenes.chain(4)
+    for _ in range(5):
+        ode_step(sc, 1e-3)
+    scene_fixture("chain4_t5", sc, 1e-3, 0.1)
+    scene_fixture("chain8_t0", scenes.chain(8), 1e-3, 0.01)
+    scene_fixture("stack2x2x2", scenes.box_stack(2, 2, 2), 5e-3, 0.01)
+    scene_fixture("stack4x4x4", scenes.box_stack(4, 4, 4, jitter=1e-3, seed=1), 5e-3, 0.01)
+    rng = np.random.default_rng(2024)
+    for k, (n, m) in enumerate(((6, 10), (20, 50), (40, 16))):
+        s, rhs = random_system(rng, n, m, connected=(k == 1))
+        d = dict(Minv=s.Minv, body0=s.body0, body1=s.body1, J0=s.J0, J1=s.J1, is_eq=s.is_eq,
+                 lo=s.lo, hi=s.hi, rhs=rhs, cfm=0.05)
+        solve_outputs(d, s, rhs, 0.05)
+        np.savez_compressed(os.path.join(OUT, "random%d.npz" % k), **d)
+        print("random%d" % k, n, m)
+
+
+if __name__ == "__main__":
+    main()
