@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/eggshell_amd.h"
+#include "dense_lcp.h"
 #include "kernels.h"
 #include "plan.h"
 
@@ -654,8 +655,17 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
                                        double *x, double *w, int32_t *ok, int32_t *pivots) {
   if (!ctx) return EGS_ERR_INVALID;
   if (N < 0 || (N > 0 && (!A || !b || !C || !lo || !hi || !x || !w))) return fail(ctx, EGS_ERR_INVALID, "NULL array");
-  (void)use_bounds; (void)ok; (void)pivots;
-  return fail(ctx, EGS_ERR_UNSUPPORTED, "dense LCP (entry 3) is not built yet");
+  if (ok) *ok = 0;
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    int piv = 0;
+    std::string msg;
+    const bool good = dense_mixed_constraints(ctx->stream, N, A, b, C, lo, hi, use_bounds != 0, x, w, &piv, &msg);
+    if (ok) *ok = good ? 1 : 0;
+    if (pivots) *pivots = piv;
+    if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "MixedConstraintsSolver did not reach a solution" : msg);
+    return EGS_OK;
+  });
 }
 
 egs_status egs_debug_plan(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,

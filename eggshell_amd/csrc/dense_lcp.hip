@@ -1,0 +1,520 @@
+// dense_lcp.hip -- dense direct LCP for gfx950: the reference's
+// Lcp::MixedConstraintsSolver (lcp.cc:276-336) and Lcp::MurtyPrincipalPivot
+// (lcp.cc:157-274) with the O(n^3) pieces on the GPU.
+//
+// Structure (all matrices row-major fp64, resident in HBM for the whole call):
+//   * One routine does every factorisation: a blocked right-looking Cholesky of
+//     the first `nf` columns of a lower-trapezoid T (extra rows below the square
+//     part ride along).  Per 64-column block: chol_panel_kernel (diagonal block
+//     factored in LDS by one wavefront, triangular solve of every 64-row slab
+//     below it) and chol_update_kernel (trailing T -= P P^T on the fp64 matrix
+//     cores, v_mfma_f64_16x16x4_f64).
+//   * MixedConstraintsSolver: permute to [E | I], append b as a last row and
+//     factor only the E columns: the trailing block IS the Schur complement
+//     A_ii - A_ie A_ee^-1 A_ei, the trailing part of the b row IS
+//     b_i - A_ie A_ee^-1 b_e, and the b row's E part is L^-1 b_e (lcp.cc:286-294).
+//   * Murty: the reference's single-index principal pivoting verbatim -- S
+//     starts all-true, x = 0, w = -b; each iteration flips the FIRST offending
+//     index (lcp.cc:36-62) and re-solves A(S,S) x_S = b_S from scratch
+//     (lcp.cc:202-203): gather + Cholesky + back substitution on the device;
+//     the flip decision, best-solution memory (lcp.cc:105-137) and the
+//     iteration cap min(1000, 2^dim) (lcp.cc:168) are evaluated per pivot from
+//     a 64-byte record read back from the device.
+// The reference factors with Eigen's pivoted LDLT / LU inverse; A is required
+// to be symmetric with positive definite A_ee and A(S,S) (true for J M^-1 J^T
+// + cfm I and for the reference's own tests); otherwise the call reports
+// failure instead of a wrong answer.
+#include "dense_lcp.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+namespace egs {
+
+namespace {
+
+constexpr int NB = 64;    // block size = wavefront size
+constexpr int LDP = 65;   // padded LDS row stride (doubles): conflict-free column walks
+
+struct HipErr : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+void chk(hipError_t e, const char *what) {
+  if (e != hipSuccess) throw HipErr(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(call) chk((call), #call)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---- blocked Cholesky ------------------------------------------------------
+// One wavefront per 64-row slab of the panel T[k0.., k0..k0+64).  Every
+// workgroup factors the diagonal block itself (in LDS; same arithmetic, so the
+// copies agree bit for bit); slab 0 writes L back, slab s > 0 solves
+// X L^T = B for its rows.  Lane i owns row i of the block / slab.
+__global__ void __launch_bounds__(64) chol_panel_kernel(double *T, int ld, int nrows, int k0, int *fail) {
+  __shared__ double sL[NB * LDP];
+  __shared__ double sX[NB * LDP];
+  const int lane = threadIdx.x;
+  const int slab = blockIdx.x;
+  for (int c = 0; c < NB; ++c) sL[lane * LDP + c] = (c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
+  __syncthreads();
+  for (int j = 0; j < NB; ++j) {
+    double s = 0.0;
+    if (lane >= j) {
+      s = sL[lane * LDP + j];
+      for (int k = 0; k < j; ++k) s = __builtin_fma(-sL[lane * LDP + k], sL[j * LDP + k], s);
+    }
+    if (lane == j) {
+      if (!(s > 0.0)) { atomicOr(fail, 1); s = 1.0; }
+      sL[j * LDP + j] = sqrt(s);
+    }
+    __syncthreads();
+    if (lane > j) sL[lane * LDP + j] = s / sL[j * LDP + j];
+    __syncthreads();
+  }
+  if (slab == 0) {
+    for (int c = 0; c <= lane; ++c) T[(size_t)(k0 + lane) * ld + k0 + c] = sL[lane * LDP + c];
+    return;
+  }
+  const int row = k0 + slab * NB + lane;
+  const bool live = row < nrows;
+  for (int c = 0; c < NB; ++c) sX[lane * LDP + c] = live ? T[(size_t)row * ld + k0 + c] : 0.0;
+  for (int j = 0; j < NB; ++j) {
+    double s = sX[lane * LDP + j];
+    for (int k = 0; k < j; ++k) s = __builtin_fma(-sX[lane * LDP + k], sL[j * LDP + k], s);
+    sX[lane * LDP + j] = s / sL[j * LDP + j];
+  }
+  if (live)
+    for (int c = 0; c < NB; ++c) T[(size_t)row * ld + k0 + c] = sX[lane * LDP + c];
+}
+
+// Trailing update on the fp64 matrix cores: for rows r >= k0+64 and columns
+// c in [k0+64, ld) with c <= r (lower trapezoid),  T[r][c] -= sum_k P[r][k] P[c][k],
+// P = T[:, k0..k0+64).  One workgroup (4 wavefronts) per 64x64 tile; each
+// wavefront owns a 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps of 4.
+// v_mfma_f64_16x16x4_f64 operand maps: A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15]; D: col = lane&15, row = (lane>>4) + 4*reg.
+__global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int nrows, int k0) {
+  const int r0 = k0 + NB + blockIdx.y * NB;
+  const int c0 = k0 + NB + blockIdx.x * NB;
+  if (c0 > r0 + NB - 1) return;  // tile entirely above the diagonal
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qr = r0 + (wave >> 1) * 32, qc = c0 + (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const double *Pa[2], *Pb[2];
+  bool va[2], vb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ra = qr + 16 * t + li, rb = qc + 16 * t + li;
+    va[t] = ra < nrows; vb[t] = rb < nrows && rb < ld;
+    Pa[t] = T + (size_t)(va[t] ? ra : 0) * ld + k0;
+    Pb[t] = T + (size_t)(vb[t] ? rb : 0) * ld + k0;
+  }
+#pragma unroll 4
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    double a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = va[t] ? Pa[t][4 * kk + lk] : 0.0;
+      b[t] = vb[t] ? Pb[t][4 * kk + lk] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
+        if (r < nrows && c < ld && c <= r) T[(size_t)r * ld + c] -= acc[ti][tj][reg];
+      }
+}
+
+// Solve L^T x = y in one workgroup: L = T[0..nf)[0..nf) lower, y = T[yrow][0..nf).
+// x is written to out[map ? map[i] : i] for i < nreal (padding rows dropped).
+__global__ void __launch_bounds__(256) back_solve_kernel(const double *T, int ld, int nf, int yrow, int nreal,
+                                                         const int *map, double *out, double *xs /*[nf] scratch*/) {
+  __shared__ double sx[NB];
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nf; i += 256) xs[i] = T[(size_t)yrow * ld + i];
+  __syncthreads();
+  for (int kb = nf - NB; kb >= 0; kb -= NB) {
+    // t_i = y_i - sum_{r >= kb+64} L[r][kb+i] x_r   (i = 0..63), 4 threads per i
+    const int i = tid & 63, part = tid >> 6;
+    double s = 0.0;
+    for (int r = kb + NB + part; r < nf; r += 4) s = __builtin_fma(T[(size_t)r * ld + kb + i], xs[r], s);
+    red[tid] = s;
+    __syncthreads();
+    if (tid < NB) sx[tid] = xs[kb + tid] - ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]));
+    __syncthreads();
+    // back substitution inside the 64x64 diagonal block (wavefront 0)
+    if (tid < NB) {
+      for (int j = NB - 1; j >= 0; --j) {
+        if (tid == j) sx[j] = sx[j] / T[(size_t)(kb + j) * ld + kb + j];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (tid < j) sx[tid] = __builtin_fma(-T[(size_t)(kb + j) * ld + kb + tid], sx[j], sx[tid]);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      xs[kb + tid] = sx[tid];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nreal; i += 256) out[map ? map[i] : i] = xs[i];
+}
+
+// ---- gathers ---------------------------------------------------------------
+// Schur-stage trapezoid: rows = nepad + ni + 1, ld = nepad + ni (see header).
+__global__ void build_schur_kernel(const double *A, const double *b, int N, const int *E, int ne, int nepad,
+                                   const int *I, int ni, double *T) {
+  const int ld = nepad + ni, rows = nepad + ni + 1;
+  const size_t total = (size_t)rows * ld;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / ld), c = (int)(idx % ld);
+    double v = 0.0;
+    const int gc = c < ne ? E[c] : (c >= nepad ? I[c - nepad] : -1);
+    if (r < ne) { if (gc >= 0 && c < ne) v = A[(size_t)E[r] * N + gc]; }
+    else if (r < nepad) v = (c == r) ? 1.0 : 0.0;
+    else if (r < nepad + ni) { if (gc >= 0) v = A[(size_t)I[r - nepad] * N + gc]; }
+    else { if (gc >= 0) v = b[gc]; }
+    T[idx] = v;
+  }
+}
+
+// lhs (ni x ni, full symmetric) and rhs from the factored trapezoid.
+__global__ void extract_schur_kernel(const double *T, int nepad, int ni, double *lhs, double *rhs) {
+  const int ld = nepad + ni;
+  const size_t total = (size_t)ni * ni;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / ni), j = (int)(idx % ni);
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    lhs[idx] = T[(size_t)(nepad + hi) * ld + nepad + lo];
+    if (i == 0) rhs[j] = T[(size_t)(nepad + ni) * ld + nepad + j];
+  }
+}
+
+// Pivot trapezoid: A(S,S) padded with an identity block, b_eff(S) as last row.
+__global__ void build_pivot_kernel(const double *lhs, int n, const int *S, int ns, int nspad, const double *beff,
+                                   double *T) {
+  const int ld = nspad, rows = nspad + 1;
+  const size_t total = (size_t)rows * ld;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / ld), c = (int)(idx % ld);
+    double v = 0.0;
+    if (r < ns) { if (c < ns) v = lhs[(size_t)S[r] * n + S[c]]; }
+    else if (r < nspad) v = (c == r) ? 1.0 : 0.0;
+    else { if (c < ns) v = beff[S[c]]; }
+    T[idx] = v;
+  }
+}
+
+// out = M v - sub  (row-major M n x n): one wavefront per row.
+__global__ void __launch_bounds__(256) gemv_minus_kernel(const double *M, int n, const double *v, const double *sub,
+                                                         double *out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double s = 0.0;
+  for (int c = lane; c < n; c += 64) s = __builtin_fma(M[(size_t)row * n + c], v[c], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) out[row] = s - sub[row];
+}
+
+// t_k = T[last][k] - sum_j T[nepad+j][k] xi[j]   (k < nepad), in place.
+__global__ void __launch_bounds__(256) xe_rhs_kernel(double *T, int nepad, int ni, const double *xi) {
+  const int ld = nepad + ni;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nepad) return;
+  double s = T[(size_t)(nepad + ni) * ld + k];
+  for (int j = 0; j < ni; ++j) s = __builtin_fma(-T[(size_t)(nepad + j) * ld + k], xi[j], s);
+  T[(size_t)(nepad + ni) * ld + k] = s;
+}
+
+// ---- Murty bookkeeping -------------------------------------------------------
+struct MurtyRecord {      // written by murty_check_kernel, read by the host each pivot
+  int first_offender;     // lowest index that must flip, or INT_MAX
+  int out_of_bounds;      // any x < lo or x > hi            (lcp.cc:66)
+  int w_bad;              // any w < 0 at x == lo or w > 0 at x == hi  (lcp.cc:72-76)
+  int pad;
+  double resid2;          // || A x - (b + w) ||^2           (lcp.cc:81-83)
+  double goodness;        // sum of the non-positive x and w (lcp.cc:107-113)
+};
+
+// x(!S) = C (the clamped bound); beff = b - A(:, !S) x(!S) is formed by the
+// caller with gemv_minus on x_clamped.  This kernel prepares x_clamped.
+__global__ void clamp_x_kernel(int n, const uint8_t *S, const double *Cb, double *xc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) xc[i] = S[i] ? 0.0 : Cb[i];
+}
+__global__ void negate_kernel(int n, const double *a, double *o) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = -a[i];
+}
+// w = S ? 0 : r   (lcp.cc:219-223), r = A x - b
+__global__ void set_w_kernel(int n, const uint8_t *S, const double *r, double *w) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = S[i] ? 0.0 : r[i];
+}
+__global__ void fill_x_clamped_kernel(int n, const uint8_t *S, const double *Cb, double *x) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && !S[i]) x[i] = Cb[i];
+}
+
+// CheckMurtySolution, lcp.cc:20-103 (single workgroup; n <= a few thousand).
+__global__ void __launch_bounds__(1024) murty_check_kernel(int n, const double *x, const double *w, const double *r,
+                                                           const uint8_t *S, const double *Cb, const double *lo,
+                                                           const double *hi, MurtyRecord *rec) {
+  __shared__ int s_first, s_oob, s_wbad;
+  __shared__ double s_res[1024], s_good[1024];
+  if (threadIdx.x == 0) { s_first = 0x7fffffff; s_oob = 0; s_wbad = 0; }
+  __syncthreads();
+  double res = 0.0, good = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double xi = x[i], wi = w[i];
+    bool off;
+    if (S[i]) off = (xi < lo[i]) || (xi > hi[i]);
+    else off = (Cb[i] == lo[i] && wi < 0) || (Cb[i] == hi[i] && wi > 0);
+    if (off) atomicMin(&s_first, i);
+    if (xi < lo[i] || xi > hi[i]) s_oob = 1;
+    if ((xi == lo[i] && wi < 0) || (xi == hi[i] && wi > 0)) s_wbad = 1;
+    const double d = r[i] - wi;   // (A x - b) - w
+    res += d * d;
+    if (!(xi > 0)) good += xi;
+    if (!(wi > 0)) good += wi;
+  }
+  s_res[threadIdx.x] = res; s_good[threadIdx.x] = good;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { s_res[threadIdx.x] += s_res[threadIdx.x + s]; s_good[threadIdx.x] += s_good[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rec->first_offender = s_first; rec->out_of_bounds = s_oob; rec->w_bad = s_wbad; rec->pad = 0;
+    rec->resid2 = s_res[0]; rec->goodness = s_good[0];
+  }
+}
+
+template <typename T>
+struct Buf {
+  T *p = nullptr;
+  explicit Buf(size_t n) { if (n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T))); }
+  ~Buf() { if (p) (void)hipFree(p); }
+  Buf(const Buf &) = delete;
+  Buf &operator=(const Buf &) = delete;
+};
+
+inline int grid1(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// Blocked Cholesky of the first nf (multiple of 64) columns of T.
+void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail) {
+  for (int k0 = 0; k0 < nf; k0 += NB) {
+    const int slabs = (nrows - k0 + NB - 1) / NB;
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(slabs), dim3(64), 0, s, T, ld, nrows, k0, fail);
+    const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
+    if (tr > 0 && tc > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tc, tr), dim3(256), 0, s, T, ld, nrows, k0);
+  }
+}
+
+// Murty on (A n x n device, b device).  Mirrors lcp.cc:157-274; box_fix as in
+// the oracle (true box problem: solve once before the first check).
+bool murty_device(hipStream_t s, int n, const double *dA, const double *db, const std::vector<double> &lo,
+                  const std::vector<double> &hi, bool box_fix, double *dx, double *dw, int *pivots_out,
+                  std::string *msg) {
+  for (int i = 0; i < n; ++i)
+    if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
+  *pivots_out = 0;
+  if (n == 0) return true;
+  const double p2 = std::pow(2.0, n);
+  const int max_iterations = p2 > 1000 ? 1000 : (int)p2;  // lcp.cc:168
+  const int npad_max = (n + NB - 1) / NB * NB;
+  Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max);
+  Buf<uint8_t> S_d(n);
+  Buf<int> idx_d(n), fail_d(1);
+  Buf<MurtyRecord> rec_d(1);
+  std::vector<uint8_t> S(n, 1);
+  std::vector<double> Cv(lo);
+  std::vector<int> idx(n);
+  HIPCHK(hipMemcpyAsync(lo_d.p, lo.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(hi_d.p, hi.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  // x = 0, w = -b, r = A x - b = -b   (lcp.cc:184-185)
+  HIPCHK(hipMemsetAsync(dx, 0, n * sizeof(double), s));
+  hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, dw);
+  hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, r.p);
+  HIPCHK(hipMemcpyAsync(bx.p, dx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(bw.p, dw, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double best_good = 0;
+  bool have_best_good = false;
+  auto upload_state = [&]() {
+    HIPCHK(hipMemcpyAsync(S_d.p, S.data(), n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(Cb.p, Cv.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  };
+  auto check = [&](const double *xx, const double *ww, const double *rr, MurtyRecord *out) {
+    hipLaunchKernelGGL(murty_check_kernel, dim3(1), dim3(1024), 0, s, n, xx, ww, rr, S_d.p, Cb.p, lo_d.p, hi_d.p, rec_d.p);
+    HIPCHK(hipMemcpyAsync(out, rec_d.p, sizeof(MurtyRecord), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  };
+  auto is_solution = [&](const MurtyRecord &rc, double tol) {
+    return rc.first_offender == 0x7fffffff && !rc.out_of_bounds && !rc.w_bad && std::sqrt(rc.resid2) <= tol;
+  };
+  auto apply_flip = [&](const MurtyRecord &rc, const std::vector<double> &xh) {
+    const int i = rc.first_offender;  // lcp.cc:36-62
+    if (S[i]) { S[i] = 0; Cv[i] = (xh[i] < lo[i]) ? lo[i] : hi[i]; }
+    else S[i] = 1;
+  };
+  upload_state();
+  MurtyRecord rc;
+  std::vector<double> xh(n);
+  int iter = 0, pivots = 0;
+  bool force = box_fix, solved = false;
+  {  // goodness of the start iterate for the best-solution memory
+    check(dx, dw, r.p, &rc);
+    best_good = rc.goodness; have_best_good = true;
+  }
+  while (iter < max_iterations) {
+    if (!force) {
+      if (is_solution(rc, 1e-9)) { solved = true; break; }
+      if (rc.first_offender == 0x7fffffff) {
+        // no index to flip but not a solution (residual / sign checks failed):
+        // the reference recomputes with unchanged S; do the same.
+      } else {
+        if (S[rc.first_offender]) HIPCHK(hipMemcpyAsync(xh.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost, s)), HIPCHK(hipStreamSynchronize(s));
+        apply_flip(rc, xh);
+        upload_state();
+      }
+    }
+    force = false;
+    // new candidate: x(S) = A(S,S)^-1 (b(S) [- A(S,!S) x(!S)])   lcp.cc:199-216
+    int ns = 0;
+    for (int i = 0; i < n; ++i) if (S[i]) idx[ns++] = i;
+    const int nspad = (ns + NB - 1) / NB * NB;
+    hipLaunchKernelGGL(clamp_x_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, Cb.p, xc.p);
+    if (box_fix) {
+      // beff = b - A xc  ->  computed as -(A xc - b)
+      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, xc.p, db, beff.p);
+      hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, beff.p, beff.p);
+    } else {
+      HIPCHK(hipMemcpyAsync(beff.p, db, n * sizeof(double), hipMemcpyDeviceToDevice, s));  // reference omits A(S,!S)x(!S)
+    }
+    HIPCHK(hipMemcpyAsync(dx, xc.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (ns > 0) {
+      HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), ns * sizeof(int), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
+                         nspad, beff.p, T.p);
+      factor(s, T.p, nspad, nspad + 1, nspad, fail_d.p);
+      hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(256), 0, s, T.p, nspad, nspad, nspad, ns, idx_d.p, dx, xs.p);
+    }
+    // r = A x - b; w(!S) = r (box_fix) or A(!S,S) x(S) - b(!S) (reference, lcp.cc:219-221)
+    if (box_fix) {
+      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
+      hipLaunchKernelGGL(set_w_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, r.p, dw);
+    } else {
+      // reference: w uses x(S) only; x(!S) = lo = 0 here so A x(S-only) == A x
+      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
+      hipLaunchKernelGGL(set_w_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, r.p, dw);
+    }
+    ++pivots;
+    check(dx, dw, r.p, &rc);
+    // lcp.cc:125-137: keep the best iterate by "goodness"
+    if (!have_best_good || rc.goodness > best_good) {
+      best_good = rc.goodness; have_best_good = true;
+      HIPCHK(hipMemcpyAsync(bx.p, dx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(bw.p, dw, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    ++iter;
+  }
+  if (!solved && iter < max_iterations) solved = is_solution(rc, 1e-9);
+  *pivots_out = pivots;
+  int fail = 0;
+  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (fail) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
+  if (solved) return true;  // x, w hold the solution iterate (== best, see lcp.cc:241)
+  // capped: return the best-seen iterate and re-check it with the looser 1e-8 (lcp.cc:241-246)
+  if (!box_fix) {
+    HIPCHK(hipMemcpyAsync(dx, bx.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(dw, bw.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
+  check(dx, dw, r.p, &rc);
+  const bool ok = is_solution(rc, 1e-8);
+  if (!ok && msg) *msg = "MurtyPrincipalPivot: iteration cap reached without a sensible solution (lcp.cc:250-252)";
+  return ok;
+}
+
+}  // namespace
+
+bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double *b, const uint8_t *C, const double *lo,
+                             const double *hi, bool use_bounds, double *x, double *w, int *pivots, std::string *msg) {
+  if (pivots) *pivots = 0;
+  if (N == 0) return true;
+  double amax = 0, asym = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < i; ++j) {
+      amax = std::max(amax, std::fabs(A[(size_t)i * N + j]));
+      asym = std::max(asym, std::fabs(A[(size_t)i * N + j] - A[(size_t)j * N + i]));
+    }
+  if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
+  std::vector<int> E, I;
+  for (int i = 0; i < N; ++i) (C[i] ? E : I).push_back(i);
+  const int ne = (int)E.size(), ni = (int)I.size();
+  const int nepad = (ne + NB - 1) / NB * NB;
+  const int ld = nepad + ni, rows = nepad + ni + 1;
+  Buf<double> dA((size_t)N * N), db(N), T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad);
+  Buf<int> dE(ne), dI(ni), fail_d(1);
+  HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
+  if (ne) HIPCHK(hipMemcpyAsync(dE.p, E.data(), ne * sizeof(int), hipMemcpyHostToDevice, s));
+  if (ni) HIPCHK(hipMemcpyAsync(dI.p, I.data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  // Schur stage: factor the E columns of [A_ee A_ei; A_ie A_ii; b^T]   (lcp.cc:286-294)
+  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE.p, ne, nepad, dI.p, ni, T.p);
+  factor(s, T.p, ld, rows, nepad, fail_d.p);
+  if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
+  int fail = 0;
+  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (fail) { if (msg) *msg = "A_ee is not positive definite"; return false; }
+  // Murty on the inequality part; the reference calls the no-bounds overload (lcp.cc:298)
+  std::vector<double> l2(ni), h2(ni);
+  for (int k = 0; k < ni; ++k) { l2[k] = use_bounds ? lo[I[k]] : 0.0; h2[k] = use_bounds ? hi[I[k]] : std::numeric_limits<double>::infinity(); }
+  int piv = 0;
+  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, xi.p, wi.p, &piv, msg);
+  if (pivots) *pivots = piv;
+  if (!ok) return false;
+  // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)
+  std::vector<double> xih(ni), wih(ni), xeh(ne);
+  if (ne) {
+    hipLaunchKernelGGL(xe_rhs_kernel, dim3((nepad + 255) / 256), dim3(256), 0, s, T.p, nepad, ni, xi.p);
+    hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(256), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p);
+    HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (ni) {
+    HIPCHK(hipMemcpyAsync(xih.data(), xi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(wih.data(), wi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  for (int i = 0; i < N; ++i) w[i] = 0.0;  // lcp.cc:332-333
+  for (int k = 0; k < ne; ++k) x[E[k]] = xeh[k];
+  for (int k = 0; k < ni; ++k) { x[I[k]] = xih[k]; w[I[k]] = wih[k]; }
+  return true;
+}
+
+}  // namespace egs

@@ -1,0 +1,206 @@
+// eggshell_api.h -- host-side C++ adapter: the reference's Body / Constraint /
+// Joint / Contact / Ensemble API for the constraint-solve path, unchanged in
+// names, argument meaning and result types, with the arithmetic behind
+//   sparse::{Jacobi,GaussSeidel,SOR}Iteration   (sparse_iterations.h:26-34)
+//   Lcp::MixedConstraintsSolver                 (lcp.h:21-23)
+//   Ensemble::Step / StepVelocities_ODE         (ensembles.cc:390-427, 563-575)
+// routed to the MI355X library through the C ABI (include/eggshell_amd.h).
+// What is mirrored here and from where:
+//   Body                body.h:13-96 (state p,v,m,R,w,I; side 0.3)
+//   Constraint          constraints.h:14-48
+//   Joint, BallAndSocketJoint   joints.h:12-50, joints.cc:3-35
+//   ContactGeometry     collision.h:12-27
+//   Contact             contact.h:11-56, contact.cc:14-117 (FrictionModel::BOX)
+//   Ensemble, Chain     ensembles.h:25-186, ensembles.cc:24-87,156-171,202-239,
+//                       429-443, 563-591, 668-707
+// Error convention differs on purpose: the reference Panics (_exit(1)); these
+// functions throw egs::Error carrying the C ABI status and message.
+#ifndef EGGSHELL_API_H
+#define EGGSHELL_API_H
+
+#include <array>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/eggshell_amd.h"
+#include "eigen_lite.h"
+
+namespace egs {
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+// Process-wide context on device 0 (created on first use).
+egs_context *DefaultContext();
+}  // namespace egs
+
+// utils.h
+Matrix3d CrossMat(const Vector3d &a);                      // utils.cc:16-24
+Matrix3d AlignVectors(const Vector3d &a, const Vector3d &b);  // utils.cc:233-237
+Matrix3d WtoR(const Vector3d &w, double dt);               // utils.cc:82-89 (as a matrix)
+
+class Body {  // body.h:13-96
+ public:
+  Body() : m_(1.0), R_(Matrix3d::Identity()) { I_ = CalculateInertia(m_); }
+  Body(const Vector3d &p, const Vector3d &v, const Matrix3d &R, const Vector3d &w)
+      : p_(p), v_(v), m_(1.0), R_(R), w_(w) { I_ = CalculateInertia(m_); }
+  Body(const Vector3d &p, const Vector3d &v, double m, const Matrix3d &R, const Vector3d &w, const Matrix3d &I)
+      : p_(p), v_(v), m_(m), R_(R), w_(w), I_(I) {}
+  const Vector3d &p() const { return p_; }
+  const Vector3d &v() const { return v_; }
+  double m() const { return m_; }
+  const Matrix3d &R() const { return R_; }
+  const Vector3d &w_g() const { return w_; }
+  const Matrix3d &I_b() const { return I_; }
+  Matrix3d I_g() const { return R_ * I_ * R_.transpose(); }
+  void SetP(const Vector3d &p) { p_ = p; }
+  void SetV(const Vector3d &v) { v_ = v; }
+  void SetR(const Matrix3d &R) { R_ = R; }
+  void SetW_GlobalFrame(const Vector3d &w) { w_ = w; }
+  Vector3d GetSideLengths() const { return Vector3d(0.3, 0.3, 0.3); }  // body.h:91
+
+ private:
+  Vector3d p_, v_;
+  double m_;
+  Matrix3d R_;
+  Vector3d w_;
+  Matrix3d I_;
+  Matrix3d CalculateInertia(double m) const;  // body.cc:19-36
+};
+
+class Constraint {  // constraints.h:14-48
+ public:
+  Constraint(std::shared_ptr<Body> b0, int i0, std::shared_ptr<Body> b1, int i1)
+      : i0_(i0), i1_(i1), b0_(std::move(b0)), b1_(std::move(b1)) {}
+  virtual ~Constraint() = default;
+  virtual VectorXd ComputeError() const = 0;
+  virtual void ComputeJ(MatrixXd *J_b0, MatrixXd *J_b1, ArrayXb *constraint_type, VectorXd *constraint_lo,
+                        VectorXd *constraint_hi) const = 0;
+  // Device-assembly descriptor (egs_constraint_kind + 7 doubles); returns false
+  // for constraint types the library cannot assemble itself (then the solver
+  // falls back to flattening ComputeJ on the host, entry 1).
+  virtual bool Describe(int32_t *kind, double data[7]) const { (void)kind; (void)data; return false; }
+  int i0_ = -1;
+  int i1_ = -1;
+
+ protected:
+  const std::shared_ptr<Body> b0_;
+  const std::shared_ptr<Body> b1_;
+};
+
+class Joint : public Constraint {  // joints.h:12-28
+ public:
+  Joint(std::shared_ptr<Body> b0, int i0, const Vector3d &c0, const Vector3d &c1)
+      : Constraint(std::move(b0), i0, nullptr, -1), c0_(c0), c1_(c1) {}
+  Joint(std::shared_ptr<Body> b0, int i0, const Vector3d &c0, std::shared_ptr<Body> b1, int i1, const Vector3d &c1)
+      : Constraint(std::move(b0), i0, std::move(b1), i1), c0_(c0), c1_(c1) {}
+
+ protected:
+  Vector3d c0_, c1_;
+};
+
+class BallAndSocketJoint : public Joint {  // joints.h:31-50
+ public:
+  using Joint::Joint;
+  VectorXd ComputeError() const override;                                   // joints.cc:3-11
+  void ComputeJ(MatrixXd *J_b0, MatrixXd *J_b1, ArrayXb *constraint_type, VectorXd *constraint_lo,
+                VectorXd *constraint_hi) const override;                    // joints.cc:13-35
+  bool Describe(int32_t *kind, double data[7]) const override;
+};
+
+struct ContactGeometry {  // collision.h:12-27
+  Vector3d position, normal;
+  double depth = 0;
+  ContactGeometry() {}
+  ContactGeometry(const Vector3d &p, const Vector3d &n, double d) : position(p), normal(n), depth(d) {}
+};
+
+class Contact : public Constraint {  // contact.h:11-56
+ public:
+  Contact(std::shared_ptr<Body> b, int index, const ContactGeometry &cg)
+      : Constraint(nullptr, -1, std::move(b), index), cg_(cg) {}
+  Contact(std::shared_ptr<Body> b0, int i0, std::shared_ptr<Body> b1, int i1, const ContactGeometry &cg)
+      : Constraint(std::move(b0), i0, std::move(b1), i1), cg_(cg) {}
+  VectorXd ComputeError() const override;                                   // contact.cc:14-22
+  void ComputeJ(MatrixXd *J_b0, MatrixXd *J_b1, ArrayXb *C, VectorXd *x_lo, VectorXd *x_hi) const override;  // :38-117
+  bool Describe(int32_t *kind, double data[7]) const override;
+
+ private:
+  const ContactGeometry cg_;
+};
+
+typedef std::vector<std::shared_ptr<Body>> ComponentsList;     // ensembles.h:19-22
+typedef std::vector<std::shared_ptr<Joint>> JointsList;
+typedef std::vector<std::shared_ptr<Contact>> ContactsList;
+typedef std::vector<std::shared_ptr<Constraint>> ConstraintsList;
+
+namespace sparse {  // sparse_iterations.h:26-34
+VectorXd JacobiIteration(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &rhs,
+                         double cfm = 0.0);
+VectorXd GaussSeidelIteration(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &rhs,
+                              double cfm = 0.0);
+VectorXd SORIteration(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &rhs,
+                      double cfm = 0.0);
+// sparse_iterations_utils.cc:697-720
+void ConstructMixedConstraints(const ConstraintsList &constraints, ArrayXb *C, VectorXd *x_lo, VectorXd *x_hi);
+// Iteration count and residual of the most recent *Iteration call (the
+// reference prints the count to stdout, sparse_iterations.cc:223-224).
+struct LastSolve { int iterations; double residual; int n_islands, n_tiles, n_global; };
+LastSolve GetLastSolve();
+}  // namespace sparse
+
+namespace Lcp {  // lcp.h:21-23
+bool MixedConstraintsSolver(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &x_lo,
+                            const VectorXd &x_hi, VectorXd &x, VectorXd &w);
+}
+
+class Ensemble {  // ensembles.h:25-186
+ public:
+  virtual ~Ensemble();
+  virtual void Init();                                                   // ensembles.cc:24-29
+  enum struct Integrator { EXPLICIT_EULER = 0, OPEN_DYNAMICS_ENGINE, IMPLICIT_MIDPOINT };
+  // Step with the switch the reference left open (kSparseImplementation,
+  // ensembles.cc:17-21) turned on: contacts as given (UpdateContacts is
+  // the caller's until the collision row is built), velocities by the
+  // matrix-free projected SOR on the GPU, positions by the midpoint rule.
+  virtual void Step(double dt, Integrator g = Integrator::OPEN_DYNAMICS_ENGINE);
+  const MatrixXd &M_inverse() const { return M_inverse_; }
+  const ConstraintsList constraints() const { return CombineConstraintsLists(); }
+  const ComponentsList &components() const { return components_; }
+  void SetContacts(const ContactsList &c) { contacts_ = c; topology_dirty_ = true; }
+  const VectorXd GetVelocities() const;                                  // ensembles.cc:429-436
+  VectorXd ComputePositionConstraintError() const;                       // ensembles.cc:156-171
+  // solver parameters (compile-time constants in the reference)
+  egs_solve_params solver_params;
+  double cfm_coeff = 0.01;                                               // kCfmCoeff, ensembles.cc:14
+  VectorXd last_lambda;
+
+ protected:
+  Ensemble();
+  int n_ = 0;
+  ComponentsList components_;
+  JointsList joints_;
+  ContactsList contacts_;
+  MatrixXd M_inverse_;
+  VectorXd external_force_torque_;
+
+ private:
+  void ConstructMassInertiaMatrixInverse();                              // ensembles.cc:202-212
+  void InitializeExternalForceTorqueVector();                            // ensembles.cc:214-222
+  ConstraintsList CombineConstraintsLists() const;                       // ensembles.cc:234-239
+  void UpdateComponentsVelocities(const VectorXd &v);                    // ensembles.cc:438-443
+  VectorXd StepVelocities_ODE(double dt, const VectorXd &v, double error_reduction_param = 0.2);  // :563-575
+  void StepPositions_ODE(double dt, const VectorXd &v, const VectorXd &v_new);                    // :577-591
+  egs_problem *problem_ = nullptr;
+  bool topology_dirty_ = true;
+};
+
+class Chain : public Ensemble {  // ensembles.h:188-198, ensembles.cc:668-707
+ public:
+  Chain(int num_links, const Vector3d &anchor_position);
+};
+
+#endif
