@@ -44,13 +44,30 @@ __device__ __forceinline__ T dot6(const T *j, const T *a) {
   return s;
 }
 
+// three-term chain over one half (linear or angular) of a 3x6 row
+template <typename T>
+__device__ __forceinline__ T dot3h(const T *j, const T *a) {
+  T s = j[0] * a[0];
+  s = tfma(j[1], a[1], s);
+  s = tfma(j[2], a[2], s);
+  return s;
+}
+// (A x)_row without cfm: (p0 + p1) + (p2 + p3), oracle row_dot
+template <typename T>
+__device__ __forceinline__ T row_dot(const T *j0, const T *a0, const T *j1, const T *a1) {
+  const T p0 = dot3h(j0, a0), p1 = dot3h(j0 + 3, a0 + 3);
+  const T p2 = dot3h(j1, a1), p3 = dot3h(j1 + 3, a1 + 3);
+  return (p0 + p1) + (p2 + p3);
+}
+
+// sparse_iterations_utils.cc:12-21, branch-free: same result for every input
+// (NaN compares false and passes through, as in the reference).
 template <typename T>
 __device__ __forceinline__ T project(T x, bool eq, T lo, T hi) {
-  if (!eq) {
-    if (x < lo) return lo;
-    else if (x > hi) return hi;
-  }
-  return x;
+  T r = x;
+  r = (x > hi) ? hi : r;
+  r = (x < lo) ? lo : r;
+  return eq ? x : r;
 }
 
 // a += B d, rows applied in order 0,1,2 (oracle acc_add)
@@ -78,7 +95,7 @@ struct Cons {
   REAL J0[18], J1[18];  // 3x6 row-major, zero for a world side
   REAL B0[18], B1[18];  // (W J^T) as 6x3 row-major
   REAL D[9];            // J0 B0 + J1 B1
-  REAL den[3];          // (D_rr + cfm) * kscale
+  REAL inv[3];          // 1 / ((D_rr + cfm) * kscale)
   REAL rhs[3], lo[3], hi[3];
   bool eq[3];
 };
@@ -129,7 +146,7 @@ __device__ __forceinline__ void load_cons(const SolveArgs<REAL> &A, int cidx, bo
     }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    c.den[r] = (c.D[4 * r] + A.cfm) * A.kscale;
+    c.inv[r] = REAL(1) / ((c.D[4 * r] + A.cfm) * A.kscale);
     c.rhs[r] = A.rhs[(size_t)cidx * 3 + r];
     c.lo[r] = A.lo[(size_t)cidx * 3 + r];
     c.hi[r] = A.hi[(size_t)cidx * 3 + r];
@@ -143,9 +160,7 @@ __device__ __forceinline__ void row_residuals(const Cons<REAL> &c, const REAL *a
                                               const REAL *x, REAL cfm, REAL *res) {
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    REAL s0 = dot6(c.J0 + 6 * r, a0);
-    REAL s1 = dot6(c.J1 + 6 * r, a1);
-    REAL full = tfma(cfm, x[r], s0 + s1);
+    REAL full = tfma(cfm, x[r], row_dot(c.J0 + 6 * r, a0, c.J1 + 6 * r, a1));
     res[r] = c.rhs[r] - full;
   }
 }
@@ -156,7 +171,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
   if (METHOD == 0) {  // Jacobi: no intra-block coupling
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      REAL xn = project(x[r] + res[r] / c.den[r], c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(res[r], c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
@@ -166,7 +181,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
       REAL t = res[r];
 #pragma unroll
       for (int l = 0; l < r; ++l) t = tfma(-c.D[3 * r + l], dx[l], t);
-      REAL xn = project(x[r] + t / c.den[r], c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
@@ -176,7 +191,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
       REAL t = res[r];
 #pragma unroll
       for (int l = 2; l > r; --l) t = tfma(-c.D[3 * r + l], dx[l], t);
-      REAL xn = project(x[r] + t / c.den[r], c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
@@ -332,9 +347,7 @@ __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL>
     lds_load6(s_acc + slot1 * 6, a1);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      REAL s0 = dot6(c.J0 + 6 * r, a0);
-      REAL s1 = dot6(c.J1 + 6 * r, a1);
-      REAL w = tfma(A.cfm, x[r], s0 + s1) - c.rhs[r];
+      REAL w = tfma(A.cfm, x[r], row_dot(c.J0 + 6 * r, a0, c.J1 + 6 * r, a1)) - c.rhs[r];
       A.x[(size_t)d.cidx * 3 + r] = x[r];
       A.wres[(size_t)d.cidx * 3 + r] = w;
     }
@@ -614,7 +627,7 @@ __global__ void __launch_bounds__(256) global_prepare_kernel(const GlobalArgs<RE
   for (int k = 0; k < 9; ++k) A.D[(size_t)g * 9 + k] = c.D[k];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    A.den[(size_t)g * 3 + r] = c.den[r];
+    A.den[(size_t)g * 3 + r] = c.inv[r];
     if (!A.resume) A.x[(size_t)d.cidx * 3 + r] = c.rhs[r];
     A.dx[(size_t)g * 3 + r] = A.resume ? REAL(0) : c.rhs[r];
   }
@@ -634,7 +647,7 @@ __device__ __forceinline__ void gload_cons(const GlobalArgs<REAL> &A, int g, con
   for (int k = 0; k < 9; ++k) c.D[k] = A.D[(size_t)g * 9 + k];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    c.den[r] = A.den[(size_t)g * 3 + r];
+    c.inv[r] = A.den[(size_t)g * 3 + r];
     c.rhs[r] = A.rhs[(size_t)d.cidx * 3 + r];
     c.lo[r] = A.lo[(size_t)d.cidx * 3 + r];
     c.hi[r] = A.hi[(size_t)d.cidx * 3 + r];
@@ -769,8 +782,7 @@ __global__ void __launch_bounds__(256) global_wres_kernel(const GlobalArgs<REAL>
       j0[q] = d.body0 >= 0 ? A.J0[(size_t)d.cidx * 18 + 6 * r + q] : REAL(0);
       j1[q] = d.body1 >= 0 ? A.J1[(size_t)d.cidx * 18 + 6 * r + q] : REAL(0);
     }
-    const REAL s0 = dot6(j0, a0), s1 = dot6(j1, a1);
-    A.wres[(size_t)d.cidx * 3 + r] = tfma(A.cfm, A.x[(size_t)d.cidx * 3 + r], s0 + s1) - A.rhs[(size_t)d.cidx * 3 + r];
+    A.wres[(size_t)d.cidx * 3 + r] = tfma(A.cfm, A.x[(size_t)d.cidx * 3 + r], row_dot(j0, a0, j1, a1)) - A.rhs[(size_t)d.cidx * 3 + r];
   }
 }
 
