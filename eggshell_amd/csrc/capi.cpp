@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -33,6 +34,7 @@ namespace {
 
 constexpr size_t kEventPairs = 4096;
 constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr int kQuadMaxConstraints = 32768;  // above this the 1-lane tiles fill the GPU better
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -80,6 +82,13 @@ struct egs_problem {
   // plan
   DevBuf<LaneDesc> lanes;
   DevBuf<int32_t> tile_nslots, tile_slot_off, slot_body;
+  // latency-optimised schedule (4 lanes per constraint, 64-constraint tiles);
+  // used for GS/SOR when the problem is small and every island fits a tile
+  Plan planq;
+  bool use_quad = false;
+  DevBuf<LaneDesc> q_lanes;
+  DevBuf<int32_t> q_tile_nslots, q_tile_slot_off, q_slot_body;
+  DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
   DevBuf<GlobalDesc> gcons;
   DevBuf<uint32_t> gtickets;
   // topology + state (fp64)
@@ -165,13 +174,17 @@ void record_kernel_event(egs_context *ctx, bool begin) {
 template <typename REAL>
 void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweeps, int resume) {
   egs_context *ctx = p->ctx;
+  const bool quad = p->use_quad && method != EGS_JACOBI;
   record_kernel_event(ctx, true);
-  if (p->plan.n_tiles > 0) {
+  if (quad || p->plan.n_tiles > 0) {
     SolveArgs<REAL> a;
-    a.lanes = p->lanes.p;
-    a.tile_nslots = p->tile_nslots.p;
-    a.tile_slot_off = p->tile_slot_off.p;
-    a.slot_body = p->slot_body.p;
+    a.lanes = quad ? p->q_lanes.p : p->lanes.p;
+    a.tile_nslots = quad ? p->q_tile_nslots.p : p->tile_nslots.p;
+    a.tile_slot_off = quad ? p->q_tile_slot_off.p : p->tile_slot_off.p;
+    a.slot_body = quad ? p->q_slot_body.p : p->slot_body.p;
+    a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
+    a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
+    a.body0 = p->body0.p; a.body1 = p->body1.p; a.m = p->m;
     a.Minv = reinterpret_cast<const REAL *>(p->Minv_r.p);
     a.J0 = reinterpret_cast<const REAL *>(p->J0.p);
     a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
@@ -187,11 +200,16 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.kscale = kscale;
     a.sweeps = sweeps;
     a.resume = resume;
-    a.max_slots = p->plan.max_slots;
+    a.max_slots = quad ? p->planq.max_slots : p->plan.max_slots;
     a.spin_limit = kSpinLimit;
-    launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+    if (quad) {
+      launch_cons_prepare<REAL>(a, ctx->stream);
+      launch_quad_solve<REAL>(a, method, p->planq.n_tiles, ctx->stream);
+    } else {
+      launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+    }
   }
-  if (!p->plan.global.empty()) {
+  if (!quad && !p->plan.global.empty()) {
     GlobalArgs<REAL> g;
     g.cons = p->gcons.p;
     g.mg = (int)p->plan.global.size();
@@ -273,7 +291,7 @@ egs_status validate_params(egs_context *ctx, const egs_solve_params *prm) {
 
 void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_islands = p->plan.n_islands;
-  st->n_tiles = p->plan.n_tiles;
+  st->n_tiles = p->use_quad ? p->planq.n_tiles : p->plan.n_tiles;
   st->n_global = (int32_t)p->plan.global.size();
   st->reserved = 0;
 }
@@ -466,6 +484,23 @@ egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int3
     p->slot_body.alloc(pl.slot_body.size()); upload(p->slot_body, pl.slot_body.data(), pl.slot_body.size(), s);
     p->gcons.alloc(pl.global.size()); upload(p->gcons, pl.global.data(), pl.global.size(), s);
     p->gtickets.alloc((size_t)(n > 0 ? n : 1));
+    {  // quad schedule: small problems whose islands all fit 64-constraint tiles
+      const char *env = std::getenv("EGS_QUAD");
+      const int force = env ? std::atoi(env) : -1;
+      if (m > 0 && force != 0 && (force == 1 || m <= kQuadMaxConstraints)) {
+        p->planq = build_plan(n, m, body0, body1, 64);
+        if (p->planq.global.empty()) {
+          const Plan &pq = p->planq;
+          p->use_quad = true;
+          p->q_lanes.alloc(pq.lanes.size()); upload(p->q_lanes, pq.lanes.data(), pq.lanes.size(), s);
+          p->q_tile_nslots.alloc(pq.tile_nslots.size()); upload(p->q_tile_nslots, pq.tile_nslots.data(), pq.tile_nslots.size(), s);
+          p->q_tile_slot_off.alloc(pq.tile_slot_off.size()); upload(p->q_tile_slot_off, pq.tile_slot_off.data(), pq.tile_slot_off.size(), s);
+          p->q_slot_body.alloc(pq.slot_body.size()); upload(p->q_slot_body, pq.slot_body.data(), pq.slot_body.size(), s);
+          const size_t rsz = p->real_size(), mm2 = (size_t)m;
+          p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
+        }
+      }
+    }
     {
       const size_t mg = pl.global.size(), rsz = p->real_size();
       p->gB0.alloc(mg * 18 * rsz); p->gB1.alloc(mg * 18 * rsz); p->gD.alloc(mg * 9 * rsz);

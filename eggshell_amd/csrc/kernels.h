@@ -22,6 +22,11 @@ struct SolveArgs {
   REAL *x;                     // [3m]  in (resume) / out
   REAL *acc;                   // [n][6] in (resume) / out
   REAL *wres;                  // [3m]  out: A x - rhs
+  // per-constraint derived blocks (quad kernel only), written by cons_prepare:
+  REAL *wsB0, *wsB1;           // [m][18]  W J^T as 6x3 row-major
+  REAL *wsD, *wsInv;           // [m][9], [m][3]
+  const int32_t *body0, *body1; // [m] (cons_prepare only)
+  int32_t m;
   int32_t *error_flag;
   REAL cfm, kscale;
   int32_t sweeps, resume, max_slots;
@@ -62,6 +67,11 @@ void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
 template <typename REAL>
 void launch_global_solve(const GlobalArgs<REAL> &a, hipStream_t s);
+// latency-optimised variant: 4 lanes per constraint, 64 constraints per tile
+template <typename REAL>
+void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s);
+template <typename REAL>
+void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, hipStream_t s);
 template <typename REAL>
 void launch_assemble(const AssembleArgs &a, hipStream_t s);
 // partial sums of squares by row category: out[4*blocks]

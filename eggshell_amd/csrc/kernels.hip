@@ -633,6 +633,22 @@ __global__ void __launch_bounds__(256) global_prepare_kernel(const GlobalArgs<RE
   }
 }
 
+// B = W J^T, D, 1/den for every constraint, indexed by list position (quad path).
+template <typename REAL>
+__global__ void __launch_bounds__(256) cons_prepare_kernel(const SolveArgs<REAL> A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.m) return;
+  const int b0 = A.body0[i], b1 = A.body1[i];
+  Cons<REAL> c;
+  load_cons(A, i, b0 >= 0, b1 >= 0, b0, b1, c);
+#pragma unroll
+  for (int k = 0; k < 18; ++k) { A.wsB0[(size_t)i * 18 + k] = c.B0[k]; A.wsB1[(size_t)i * 18 + k] = c.B1[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A.wsD[(size_t)i * 9 + k] = c.D[k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) A.wsInv[(size_t)i * 3 + r] = c.inv[r];
+}
+
 template <typename REAL>
 __device__ __forceinline__ void gload_cons(const GlobalArgs<REAL> &A, int g, const GlobalDesc &d, Cons<REAL> &c) {
   const bool has0 = d.body0 >= 0, has1 = d.body1 >= 0;
@@ -863,9 +879,16 @@ void launch_global_solve(const GlobalArgs<REAL> &a0, hipStream_t s) {
   hipLaunchKernelGGL((global_wres_kernel<REAL>), dim3(flat_blocks), dim3(256), 0, s, a);
 }
 
+template <typename REAL>
+void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s) {
+  if (a.m <= 0) return;
+  hipLaunchKernelGGL((cons_prepare_kernel<REAL>), dim3((a.m + 255) / 256), dim3(256), 0, s, a);
+}
+
 #define EGS_INSTANTIATE(REAL)                                                                                \
   template void launch_tile_solve<REAL>(const SolveArgs<REAL> &, int, int, int, hipStream_t);                \
   template void launch_global_solve<REAL>(const GlobalArgs<REAL> &, hipStream_t);                            \
+  template void launch_cons_prepare<REAL>(const SolveArgs<REAL> &, hipStream_t);                            \
   template void launch_assemble<REAL>(const AssembleArgs &, hipStream_t);                                    \
   template void launch_residual_partials<REAL>(int, const REAL *, const REAL *, const REAL *, const REAL *,  \
                                                const uint8_t *, double *, int, hipStream_t);                 \

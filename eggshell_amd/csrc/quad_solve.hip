@@ -1,0 +1,305 @@
+// quad_solve.hip -- latency-optimised projected Gauss-Seidel / backward SOR:
+// FOUR lanes per constraint.  Used when the problem under-fills the GPU (one
+// ensemble, a few piles): the dependency chain of an island, not throughput,
+// sets the step time, so each update is made as short as possible.
+//
+// Lane q of a quad owns one quarter of the 3x12 Jacobian row block:
+//   q = 0: body0 linear   q = 1: body0 angular   q = 2: body1 linear   q = 3: body1 angular
+// i.e. 3 accumulator components, 9 J entries and 9 entries of B = M^-1 J^T.
+// A row product J_r . a is four 3-term fma chains combined by a 2-step quad
+// butterfly (DPP quad_perm) as (p0 + p1) + (p2 + p3) -- exactly the order of
+// the oracle's row_dot, so results stay bit-identical to the 1-lane kernel and
+// to the CPU oracle.  The 3-row projected solve is done redundantly by the four
+// lanes (identical inputs, identical bits); each lane then updates its own 3
+// accumulator components in LDS.  Ordering between constraints is the same
+// per-body ticket protocol as tile_solve_kernel (see kernels.hip).
+// Tile = 64 constraints = one 256-thread workgroup.
+#include "kernels.h"
+
+namespace egs {
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
+template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T project(T x, bool eq, T lo, T hi) {  // sparse_iterations_utils.cc:12-21
+  T r = x;
+  r = (x > hi) ? hi : r;
+  r = (x < lo) ? lo : r;
+  return eq ? x : r;
+}
+
+// quad_perm DPP: value of lane (l ^ 1) / (l ^ 2) inside each group of 4 lanes
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+constexpr int kXor1 = 0xB1;  // quad_perm [1,0,3,2]
+constexpr int kXor2 = 0x4E;  // quad_perm [2,3,0,1]
+
+template <typename T>
+__device__ __forceinline__ T quad_sum(T p) {  // (p0 + p1) + (p2 + p3) on every lane of the quad
+  p = p + dpp<kXor1>(p);
+  p = p + dpp<kXor2>(p);
+  return p;
+}
+
+__device__ __forceinline__ unsigned lds_load_acquire(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- ordered LDS hand-off, hand-placed ---------------------------------------
+// A wavefront's DS instructions execute in issue order.  Consumer: ticket load,
+// then the 3 accumulator loads, ONE wait for all four -- if the ticket matches,
+// the accumulators read after it are current (nobody else may write this body
+// before we bump its ticket).  Producer: accumulator stores, then the ticket
+// store; no wait in between.  (volatile C++ accesses were tried first: hipcc
+// lowers them to flat sc0 sc1 loads with a vmcnt(0) after each.)
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void poll3(unsigned tick_addr, unsigned acc_addr, unsigned &t, double (&a)[3]) {
+  asm volatile(
+      "ds_read_b32 %0, %4\n\t"
+      "ds_read_b64 %1, %5\n\t"
+      "ds_read_b64 %2, %5 offset:8\n\t"
+      "ds_read_b64 %3, %5 offset:16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+      : "v"(tick_addr), "v"(acc_addr)
+      : "memory");
+}
+__device__ __forceinline__ void poll3(unsigned tick_addr, unsigned acc_addr, unsigned &t, float (&a)[3]) {
+  asm volatile(
+      "ds_read_b32 %0, %4\n\t"
+      "ds_read_b32 %1, %5\n\t"
+      "ds_read_b32 %2, %5 offset:4\n\t"
+      "ds_read_b32 %3, %5 offset:8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+      : "v"(tick_addr), "v"(acc_addr)
+      : "memory");
+}
+__device__ __forceinline__ void store3(unsigned acc_addr, const double (&a)[3]) {
+  asm volatile(
+      "ds_write_b64 %0, %1\n\t"
+      "ds_write_b64 %0, %2 offset:8\n\t"
+      "ds_write_b64 %0, %3 offset:16"
+      :: "v"(acc_addr), "v"(a[0]), "v"(a[1]), "v"(a[2])
+      : "memory");
+}
+__device__ __forceinline__ void store3(unsigned acc_addr, const float (&a)[3]) {
+  asm volatile(
+      "ds_write_b32 %0, %1\n\t"
+      "ds_write_b32 %0, %2 offset:4\n\t"
+      "ds_write_b32 %0, %3 offset:8"
+      :: "v"(acc_addr), "v"(a[0]), "v"(a[1]), "v"(a[2])
+      : "memory");
+}
+__device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"(tick_addr), "v"(v) : "memory");
+}
+
+template <typename REAL, int METHOD>
+__global__ void __launch_bounds__(256, 4) quad_solve_kernel(const SolveArgs<REAL> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  REAL *s_acc = reinterpret_cast<REAL *>(smem);
+  unsigned *s_tick = reinterpret_cast<unsigned *>(smem + (size_t)A.max_slots * 6 * sizeof(REAL));
+
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int q = tid & 3, side = q >> 1, half = q & 1;
+  const int nslots = A.tile_nslots[tile];
+  const int32_t *slot_body = A.slot_body + A.tile_slot_off[tile];
+  for (int s = tid; s < nslots; s += 256) {
+    const int body = slot_body[s];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_acc[s * 6 + k] = (A.resume && body >= 0) ? A.acc[(size_t)body * 6 + k] : REAL(0);
+    s_tick[s] = 0u;
+  }
+
+  const LaneDesc d = A.lanes[(size_t)tile * 64 + (tid >> 2)];
+  const bool active = d.cidx >= 0;
+  const int slot = side ? d.slot1 : d.slot0;
+  const bool has = active && slot != 0;            // this lane's body is a real body
+  const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
+  REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
+  unsigned *my_tick = s_tick + slot;
+
+  REAL Jh[9], Bh[9], Dl[3], inv[3], rhs[3], lo[3], hi[3], x[3];
+  bool eq[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { Jh[k] = REAL(0); Bh[k] = REAL(0); }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { Dl[r] = inv[r] = rhs[r] = lo[r] = hi[r] = x[r] = REAL(0); eq[r] = true; }
+  if (active) {
+    const size_t c = (size_t)d.cidx;
+    if (has) {
+      const REAL *J = (side ? A.J1 : A.J0) + c * 18 + 3 * half;
+      const REAL *B = (side ? A.wsB1 : A.wsB0) + c * 18 + 9 * half;  // rows 3*half .. 3*half+2 of the 6x3
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Jh[3 * r + k] = J[6 * r + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Bh[k] = B[k];
+    }
+    const REAL *D = A.wsD + c * 9;
+    if (METHOD == 1) { Dl[0] = D[3]; Dl[1] = D[6]; Dl[2] = D[7]; }   // D10, D20, D21
+    else { Dl[0] = D[1]; Dl[1] = D[2]; Dl[2] = D[5]; }               // D01, D02, D12
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      inv[r] = A.wsInv[c * 3 + r];
+      rhs[r] = A.rhs[c * 3 + r];
+      lo[r] = A.lo[c * 3 + r];
+      hi[r] = A.hi[c * 3 + r];
+      eq[r] = A.is_eq[c * 3 + r] != 0;
+      x[r] = A.resume ? A.x[c * 3 + r] : rhs[r];
+    }
+  }
+  __syncthreads();
+
+  bool ok = true;
+  const unsigned base = A.resume ? 0u : cnt;
+  if (!A.resume) {
+    // accumulators from x0 = rhs (sparse_iterations.cc:202), list order per body
+    bool pending = has;
+    unsigned spins = 0;
+    while (pending) {
+      if (lds_load_acquire(my_tick) == pos) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          REAL t = tfma(Bh[3 * k + 0], x[0], my_acc[k]);
+          t = tfma(Bh[3 * k + 1], x[1], t);
+          t = tfma(Bh[3 * k + 2], x[2], t);
+          my_acc[k] = t;
+        }
+        if (half == 0) lds_store_release(my_tick, pos + 1u);
+        pending = false;
+      } else if (++spins > A.spin_limit) {
+        ok = false;
+        pending = false;
+      }
+    }
+    __syncthreads();
+  }
+
+  {
+    const unsigned ord = (METHOD == 2) ? cnt - 1u - pos : pos;
+    unsigned want = base + ord;
+    int sweep = 1;
+    unsigned spins = 0;
+    bool alive = active && A.sweeps >= 1;
+    const unsigned tick_addr = lds_addr(my_tick), acc_addr = lds_addr(my_acc);
+    while (alive) {
+      unsigned t;
+      REAL a[3];
+      poll3(tick_addr, acc_addr, t, a);
+      int rdy = (!has || t == want) ? 1 : 0;
+      rdy &= dpp_i<kXor1>(rdy);
+      rdy &= dpp_i<kXor2>(rdy);
+      if (rdy) {
+        REAL res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          REAL p = Jh[3 * r] * a[0];
+          p = tfma(Jh[3 * r + 1], a[1], p);
+          p = tfma(Jh[3 * r + 2], a[2], p);
+          const REAL full = tfma(A.cfm, x[r], quad_sum(p));
+          res[r] = rhs[r] - full;
+        }
+        if (METHOD == 1) {
+          REAL t0 = res[0];
+          REAL xn = project(tfma(t0, inv[0], x[0]), eq[0], lo[0], hi[0]);
+          dx[0] = xn - x[0]; x[0] = xn;
+          REAL t1 = tfma(-Dl[0], dx[0], res[1]);
+          xn = project(tfma(t1, inv[1], x[1]), eq[1], lo[1], hi[1]);
+          dx[1] = xn - x[1]; x[1] = xn;
+          REAL t2 = tfma(-Dl[1], dx[0], res[2]);
+          t2 = tfma(-Dl[2], dx[1], t2);
+          xn = project(tfma(t2, inv[2], x[2]), eq[2], lo[2], hi[2]);
+          dx[2] = xn - x[2]; x[2] = xn;
+        } else {
+          REAL t2 = res[2];
+          REAL xn = project(tfma(t2, inv[2], x[2]), eq[2], lo[2], hi[2]);
+          dx[2] = xn - x[2]; x[2] = xn;
+          REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
+          xn = project(tfma(t1, inv[1], x[1]), eq[1], lo[1], hi[1]);
+          dx[1] = xn - x[1]; x[1] = xn;
+          REAL t0 = tfma(-Dl[1], dx[2], res[0]);                 // D02
+          t0 = tfma(-Dl[0], dx[1], t0);                          // D01
+          xn = project(tfma(t0, inv[0], x[0]), eq[0], lo[0], hi[0]);
+          dx[0] = xn - x[0]; x[0] = xn;
+        }
+        if (has) {
+          REAL an[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            REAL u = tfma(Bh[3 * k + 0], dx[0], a[k]);
+            u = tfma(Bh[3 * k + 1], dx[1], u);
+            an[k] = tfma(Bh[3 * k + 2], dx[2], u);
+          }
+          store3(acc_addr, an);
+          if (half == 0) store_tick(tick_addr, want + 1u);
+        }
+        want += cnt;
+        spins = 0;
+        alive = ++sweep <= A.sweeps;
+      } else if (++spins > A.spin_limit) {
+        ok = false;
+        alive = false;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (!ok) atomicOr(A.error_flag, 1);
+
+  if (active) {  // lambda and w = A x - rhs with the final accumulators
+    REAL a[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] = my_acc[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      REAL p = Jh[3 * r] * a[0];
+      p = tfma(Jh[3 * r + 1], a[1], p);
+      p = tfma(Jh[3 * r + 2], a[2], p);
+      const REAL w = tfma(A.cfm, x[r], quad_sum(p)) - rhs[r];
+      if (q == 0) {
+        A.x[(size_t)d.cidx * 3 + r] = x[r];
+        A.wres[(size_t)d.cidx * 3 + r] = w;
+      }
+    }
+  }
+  for (int s = tid + 1; s < nslots; s += 256) {
+    const int body = slot_body[s];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
+  }
+}
+
+}  // namespace
+
+template <typename REAL>
+void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, hipStream_t s) {
+  if (n_tiles <= 0) return;
+  const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
+  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1>), dim3(n_tiles), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2>), dim3(n_tiles), dim3(256), lds, s, a);
+}
+
+template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, hipStream_t);
+template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, hipStream_t);
+
+}  // namespace egs

@@ -180,3 +180,30 @@ def test_invalid_arguments_do_not_crash(ctx):
         pr.solve(capi.params(method=9))
     assert e.value.status == capi.ERR_INVALID
     pr.close()
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_quad_and_single_lane_schedules_agree(ctx, method, monkeypatch):
+    """The latency-optimised 4-lanes-per-constraint kernel (EGS_QUAD=1) and the
+    1-lane tile kernel (EGS_QUAD=0) give the oracle's bits on the same inputs:
+    C2 pile, Chain(8), random graphs with islands <= 64 constraints, fp32."""
+    rng = np.random.default_rng(40)
+    cases = [system_from_scene(scenes.box_stack(8, 8, 4))[0], system_from_scene(scenes.chain(8))[0],
+             system_from_scene(scenes.concat([scenes.chain(int(k)) for k in rng.integers(1, 60, 12)]))[0]]
+    for s in cases:
+        rhs = rng.uniform(-1, 1, 3 * s.m)
+        for K in (0, 1, 9, 50):
+            xf, af, _, rf = orc.fast_iterate(s, rhs, 0.02, method, max_iters=K, tol=0.0)
+            for quad in ("0", "1"):
+                monkeypatch.setenv("EGS_QUAD", quad)
+                x, a, st = gpu_solve(ctx, s, rhs, 0.02, method, K)
+                assert st.status == capi.OK
+                assert same_bits(x, xf) and same_bits(a, af), (quad, K)
+                assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+        monkeypatch.setenv("EGS_QUAD", "1")
+        x, a, st = gpu_solve(ctx, s, rhs, 0.1, method, 500, tol=1e-9)
+        xf, af, it, rf = orc.fast_iterate(s, rhs, 0.1, method, max_iters=500, tol=1e-9)
+        assert st.iterations == it and same_bits(x, xf)
+        x32, a32, st = gpu_solve(ctx, s, rhs, 0.02, method, 20, precision=capi.F32)
+        xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.02, method, max_iters=20)
+        assert same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
