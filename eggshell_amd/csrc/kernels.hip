@@ -245,6 +245,72 @@ __device__ __forceinline__ bool ordered_accumulate(REAL *s_acc, unsigned *s_tick
   return ok;
 }
 
+// ---- ordered LDS hand-off, hand-placed (see quad_solve.hip) ------------------
+// DS instructions of a wavefront execute in issue order: both ticket loads, then
+// the accumulator loads, ONE wait; stores of the accumulators, then the tickets.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
+                                       unsigned &t1, double (&a0)[6], double (&a1)[6]) {
+  d2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b32 %0, %8\n\t"
+      "ds_read_b32 %1, %9\n\t"
+      "ds_read_b128 %2, %10\n\t"
+      "ds_read_b128 %3, %10 offset:16\n\t"
+      "ds_read_b128 %4, %10 offset:32\n\t"
+      "ds_read_b128 %5, %11\n\t"
+      "ds_read_b128 %6, %11 offset:16\n\t"
+      "ds_read_b128 %7, %11 offset:32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
+      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
+      : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
+__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
+                                       unsigned &t1, float (&a0)[6], float (&a1)[6]) {
+  f2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b32 %0, %8\n\t"
+      "ds_read_b32 %1, %9\n\t"
+      "ds_read_b64 %2, %10\n\t"
+      "ds_read_b64 %3, %10 offset:8\n\t"
+      "ds_read_b64 %4, %10 offset:16\n\t"
+      "ds_read_b64 %5, %11\n\t"
+      "ds_read_b64 %6, %11 offset:8\n\t"
+      "ds_read_b64 %7, %11 offset:16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
+      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
+      : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
+__device__ __forceinline__ void store6(unsigned ac, const double (&a)[6]) {
+  d2_t u0 = {a[0], a[1]}, u1 = {a[2], a[3]}, u2 = {a[4], a[5]};
+  asm volatile(
+      "ds_write_b128 %0, %1\n\t"
+      "ds_write_b128 %0, %2 offset:16\n\t"
+      "ds_write_b128 %0, %3 offset:32"
+      :: "v"(ac), "v"(u0), "v"(u1), "v"(u2) : "memory");
+}
+__device__ __forceinline__ void store6(unsigned ac, const float (&a)[6]) {
+  f2_t u0 = {a[0], a[1]}, u1 = {a[2], a[3]}, u2 = {a[4], a[5]};
+  asm volatile(
+      "ds_write_b64 %0, %1\n\t"
+      "ds_write_b64 %0, %2 offset:8\n\t"
+      "ds_write_b64 %0, %3 offset:16"
+      :: "v"(ac), "v"(u0), "v"(u1), "v"(u2) : "memory");
+}
+__device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"(tick_addr), "v"(v) : "memory");
+}
+
 template <typename REAL, int BLOCK, int METHOD>
 __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -312,20 +378,21 @@ __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL>
     int sweep = 1;
     unsigned spins = 0;
     bool alive = active && A.sweeps >= 1;
+    const unsigned tk0 = lds_addr(s_tick + slot0), tk1 = lds_addr(s_tick + slot1);
+    const unsigned ac0 = lds_addr(s_acc + slot0 * 6), ac1 = lds_addr(s_acc + slot1 * 6);
     while (alive) {
-      const unsigned t0 = has0 ? lds_load_acquire(s_tick + slot0) : want0;
-      const unsigned t1 = has1 ? lds_load_acquire(s_tick + slot1) : want1;
-      const bool ready = (t0 == want0) && (t1 == want1);
+      unsigned t0, t1;
+      REAL a0[6], a1[6];
+      poll12(tk0, tk1, ac0, ac1, t0, t1, a0, a1);   // world slot 0: ticket ignored, zeros
+      const bool ready = (!has0 || t0 == want0) && (!has1 || t1 == want1);
       if (ready) {
-        REAL a0[6], a1[6], res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
-        lds_load6(s_acc + slot0 * 6, a0);
-        lds_load6(s_acc + slot1 * 6, a1);
+        REAL res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
         row_residuals(c, a0, a1, x, A.cfm, res);
         update_rows<REAL, METHOD>(c, res, x, dx);
-        if (has0) { acc_add(a0, c.B0, dx); lds_store6(s_acc + slot0 * 6, a0); }
-        if (has1) { acc_add(a1, c.B1, dx); lds_store6(s_acc + slot1 * 6, a1); }
-        if (has0) lds_store_release(s_tick + slot0, want0 + 1);
-        if (has1) lds_store_release(s_tick + slot1, want1 + 1);
+        if (has0) { acc_add(a0, c.B0, dx); store6(ac0, a0); }
+        if (has1) { acc_add(a1, c.B1, dx); store6(ac1, a1); }
+        if (has0) store_tick(tk0, want0 + 1);
+        if (has1) store_tick(tk1, want1 + 1);
         want0 += cnt0; want1 += cnt1;
         spins = 0;
         alive = ++sweep <= A.sweeps;
@@ -335,6 +402,7 @@ __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL>
       }
       if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
