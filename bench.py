@@ -56,6 +56,23 @@ def host_mass_and_force(sc):
     return Minv.reshape(n, 36), f
 
 
+def measured_traffic_per_contact(kernel):
+    """HBM bytes per contact per launch of the solve kernel, measured with
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH_SIZE
+    correction applied) on this same command; see profiles/*/pmc_traffic.json."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            v = d["hbm_bytes_per_contact_per_launch"].get(kernel)
+            if v:
+                best = (float(v), os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(workload, budget_s):
     """Single-thread CPU port (oracle/, the fast O(nnz) sequential PGS in list
     order + assembly + velocity update) on ONE pile of the same workload."""
@@ -151,6 +168,9 @@ def main():
         kernel_ms = ksum_ms / max(klaunches, 1)
         alg_bytes = float(m) * sweeps * BYTES_PER_CONTACT_SWEEP[prec]   # per launch (one rank's batch)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        quad = st.n_tiles * 64 >= m and st.n_tiles * 256 > 4 * m - 1  # 64-constraint tiles = quad schedule
+        kernel = "quad_solve_kernel" if quad else "tile_solve_kernel"
+        traffic = measured_traffic_per_contact("tile_solve_kernel")
         out = {
             "metric": "constraint_solve_steps_per_sec",
             "value": units / el,
@@ -180,8 +200,11 @@ def main():
             "failed": failed,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "tile_solve_kernel", "kernel_ms": kernel_ms, "launches": klaunches,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (traffic[0] * m) if traffic else None,
+                "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                   "WRITE_SIZE, measured on the 16-pile run)" % (traffic[1], traffic[0])) if traffic else None,
+                "kernel": kernel, "kernel_ms": kernel_ms, "launches": klaunches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "algorithmic bytes = contacts x sweeps x %d B (SURVEY 8d); J blocks and body accumulators "
                         "stay in VGPRs/LDS across sweeps, so the achieved figure can exceed HBM peak"
