@@ -168,7 +168,7 @@ def main():
         kernel_ms = ksum_ms / max(klaunches, 1)
         alg_bytes = float(m) * sweeps * BYTES_PER_CONTACT_SWEEP[prec]   # per launch (one rank's batch)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        quad = st.n_tiles * 64 >= m and st.n_tiles * 256 > 4 * m - 1  # 64-constraint tiles = quad schedule
+        quad = st.reserved == 1   # 4-lanes-per-constraint schedule (small problems)
         kernel = "quad_solve_kernel" if quad else "tile_solve_kernel"
         traffic = measured_traffic_per_contact("tile_solve_kernel")
         out = {

@@ -293,7 +293,7 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_islands = p->plan.n_islands;
   st->n_tiles = p->use_quad ? p->planq.n_tiles : p->plan.n_tiles;
   st->n_global = (int32_t)p->plan.global.size();
-  st->reserved = 0;
+  st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
 }
 
 // The solve driver: sparse_iterations.cc:148-226.

@@ -74,7 +74,7 @@ typedef struct {
   int32_t n_islands;   /* connected components of the constraint graph */
   int32_t n_tiles;     /* workgroup-resident tiles */
   int32_t n_global;    /* constraints solved by the cross-workgroup path */
-  int32_t reserved;
+  int32_t reserved;    /* 1 = latency schedule (4 lanes per constraint) in use */
 } egs_solve_stats;
 
 void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */
