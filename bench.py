@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
+    ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank, world, local = egs_dist.env_rank_world()
@@ -116,10 +119,10 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch
     import torch.distributed as tdist
+    dev = 0 if (world == 1 or args.share_device0) else local
     if world > 1:
-        torch.cuda.set_device(local)
-        egs_dist.init_process_group("nccl")
-    dev = local if world > 1 else 0
+        torch.cuda.set_device(dev)
+        egs_dist.init_process_group(args.dist_backend)
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
 
     nx, ny, nz, sweeps, prec, dt = WORKLOADS[args.workload]
@@ -162,7 +165,7 @@ def main():
 
     el, units, citers, resid, failed = egs_dist.reduce_stats(
         elapsed, args.batch * args.steps, float(m) * sweeps * args.steps, st.residual, st.status != capi.OK,
-        device=("cuda:%d" % dev) if world > 1 else None)
+        device=("cuda:%d" % dev) if (world > 1 and args.dist_backend == "nccl") else None)
 
     if rank == 0:
         kernel_ms = ksum_ms / max(klaunches, 1)
