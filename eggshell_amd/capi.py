@@ -24,6 +24,7 @@ EXPORTS = [
     "egs_problem_solve", "egs_problem_get_lambda", "egs_problem_get_accumulators",
     "egs_problem_set_state", "egs_problem_set_constraints", "egs_problem_assemble",
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
+    "egs_problem_advance", "egs_problem_get_state",
     "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
 ]
 
@@ -212,6 +213,14 @@ class Problem:
         v = np.zeros((self.n, 6))
         self.ctx.check(load().egs_problem_get_velocity(self.h, _p(v)))
         return v
+
+    def advance(self, dt):
+        self.ctx.check(load().egs_problem_advance(self.h, C.c_double(dt)))
+
+    def state(self):
+        pos = np.zeros((self.n, 3)); R = np.zeros((self.n, 9)); v = np.zeros((self.n, 3)); w = np.zeros((self.n, 3))
+        self.ctx.check(load().egs_problem_get_state(self.h, _p(pos), _p(R), _p(v), _p(w)))
+        return pos, R, v, w
 
     def blocks(self):
         m = self.m

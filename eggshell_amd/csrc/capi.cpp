@@ -653,6 +653,30 @@ egs_status egs_problem_get_velocity(egs_problem *p, double *v6) {
   });
 }
 
+egs_status egs_problem_advance(egs_problem *p, double dt) {
+  if (!p) return EGS_ERR_INVALID;
+  if (!p->have_state) return fail(p->ctx, EGS_ERR_INVALID, "set_state and step first");
+  return guarded(p->ctx, [&]() -> egs_status {
+    launch_advance(p->n, p->pos.p, p->R.p, p->v.p, p->w.p, p->v6.p, dt, p->ctx->stream);
+    HIPCHK(hipGetLastError());
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_get_state(egs_problem *p, double *pos, double *R, double *v, double *w) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    const size_t n = p->n;
+    hipStream_t s = p->ctx->stream;
+    if (pos && n) HIPCHK(hipMemcpyAsync(pos, p->pos.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (R && n) HIPCHK(hipMemcpyAsync(R, p->R.p, n * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (v && n) HIPCHK(hipMemcpyAsync(v, p->v.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (w && n) HIPCHK(hipMemcpyAsync(w, p->w.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return EGS_OK;
+  });
+}
+
 egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats) {
   if (!p || !stats) return EGS_ERR_INVALID;
   return guarded(p->ctx, [&]() -> egs_status {

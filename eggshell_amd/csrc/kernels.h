@@ -87,6 +87,9 @@ void launch_velocity(int n, const double *v, const double *w,
 template <typename REAL>
 void launch_convert_minv(int count, const double *src, REAL *dst, hipStream_t s);
 
+void launch_advance(int n, double *pos, double *R, double *v, double *w, const double *v6, double dt,
+                    hipStream_t s);
+
 constexpr int kResidualBlocks = 64;
 
 }  // namespace egs

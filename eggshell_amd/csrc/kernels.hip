@@ -475,6 +475,45 @@ __global__ void __launch_bounds__(256) velocity_kernel(int n, const double *v, c
   }
 }
 
+// StepPositions_ODE (ensembles.cc:577-591): p += dt (v + v_new)/2,
+// R = Q(dt (w + w_new)/2) R with Q = WtoQ (utils.cc:82-89); then the new
+// velocities become the body state for the next step.
+__global__ void __launch_bounds__(256) advance_kernel(int n, double *pos, double *R, double *v, double *w,
+                                                      const double *v6, double dt) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  double wm[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double vm = (v[(size_t)b * 3 + k] + v6[(size_t)b * 6 + k]) / 2.0;
+    pos[(size_t)b * 3 + k] = pos[(size_t)b * 3 + k] + dt * vm;
+    wm[k] = (w[(size_t)b * 3 + k] + v6[(size_t)b * 6 + 3 + k]) / 2.0;
+  }
+  const double n2 = (wm[0] * wm[0] + wm[1] * wm[1]) + wm[2] * wm[2];
+  const double nrm = sqrt(n2);
+  double ax[3] = {wm[0], wm[1], wm[2]};
+  if (n2 > 0) { ax[0] = wm[0] / nrm; ax[1] = wm[1] / nrm; ax[2] = wm[2] / nrm; }
+  const double half = 0.5 * (nrm * dt);
+  const double sn = sin(half), cs = cos(half);
+  const double qw = cs, qx = sn * ax[0], qy = sn * ax[1], qz = sn * ax[2];
+  const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const double Q[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx,
+                       txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+  double Ro[9], Rn[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ro[k] = R[(size_t)b * 9 + k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rn[3 * i + j] = (Q[3 * i] * Ro[j] + Q[3 * i + 1] * Ro[3 + j]) + Q[3 * i + 2] * Ro[6 + j];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)b * 9 + k] = Rn[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { v[(size_t)b * 3 + k] = v6[(size_t)b * 6 + k]; w[(size_t)b * 3 + k] = v6[(size_t)b * 6 + 3 + k]; }
+}
+
 template <typename REAL>
 __global__ void __launch_bounds__(256) convert_kernel(int count, const double *src, REAL *dst) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -908,6 +947,11 @@ void launch_velocity(int n, const double *v, const double *w, const double *Minv
                      const REAL *acc, double dt, double *v6, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL((velocity_kernel<REAL>), dim3((n + 255) / 256), dim3(256), 0, s, n, v, w, Minv, f_ext, acc, dt, v6);
+}
+
+void launch_advance(int n, double *pos, double *R, double *v, double *w, const double *v6, double dt, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(advance_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, pos, R, v, w, v6, dt);
 }
 
 template <typename REAL>

@@ -159,6 +159,12 @@ egs_status egs_problem_get_blocks(egs_problem *p, double *J0, double *J1,
                                   uint8_t *is_eq, double *lo, double *hi,
                                   double *rhs, double *err);
 egs_status egs_problem_get_velocity(egs_problem *p, double *v6 /*[n][6]*/);
+/* Ensemble::StepPositions_ODE (ensembles.cc:577-591) on the device, after
+ * egs_problem_step: p += dt (v + v_new)/2, R = WtoQ((w + w_new)/2, dt) R
+ * (utils.cc:82-89), then v, w <- v_new, so the body state never leaves the
+ * GPU between steps while the contact set is unchanged. */
+egs_status egs_problem_advance(egs_problem *p, double dt);
+egs_status egs_problem_get_state(egs_problem *p, double *pos, double *R, double *v, double *w);
 /* fills stats->residual/iterations of the last solve (synchronises) */
 egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats);
 

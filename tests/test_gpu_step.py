@@ -163,3 +163,47 @@ def test_converged_c2_satisfies_reference_check(ctx):
                   s.hi.reshape(-1, 3)[col].reshape(-1))
     r = orc.lit_residual(sub, rhs.reshape(-1, 3)[col].reshape(-1), x.reshape(-1, 3)[col].reshape(-1), 0.1)
     assert r <= 1e-9
+
+
+def test_device_resident_chain_trajectory(ctx):
+    """Chain(8), 20 steps entirely on the device (assemble + SOR to 1e-9 +
+    velocity + StepPositions_ODE, ensembles.cc:390-427 with the sparse switch):
+    state never leaves the GPU; compared after every 5 steps with the
+    reference's live dense path (joints only, so both reference solvers agree)
+    restated from oracle pieces."""
+    from helpers import ode_step
+    sc = scenes.chain(8)
+    ref = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in sc.items()}
+    pr, Minv, f_ext = make_problem(ctx, sc)
+    prm = capi.params(method=capi.SOR, max_iters=5000, tol=1e-11, cfm=0.0)
+    for step in range(1, 21):
+        pr.step(1e-3, 0.2, prm)
+        pr.advance(1e-3)
+        ode_step(ref, 1e-3)
+        if step % 5 == 0:
+            pos, R, v, w = pr.state()
+            assert np.abs(pos - ref["p"]).max() < 1e-9
+            assert np.abs(R - ref["R"]).max() < 1e-9
+            assert np.abs(v - ref["v"]).max() < 1e-6 and np.abs(w - ref["w"]).max() < 1e-6
+    assert np.abs(pos[:, 2] - 2.0).max() > 1e-5      # the chain did swing
+    pr.close()
+
+
+def test_advance_matches_oracle_position_update(ctx):
+    """One StepPositions_ODE with random velocities: p exact to rounding, R to
+    1e-15 (device sin/cos vs libm)."""
+    rng = np.random.default_rng(50)
+    sc = scenes.box_stack(3, 3, 2)
+    sc["v"] = rng.uniform(-1, 1, sc["v"].shape); sc["w"] = rng.uniform(-3, 3, sc["w"].shape)
+    sc["w"][0] = 0.0                                   # zero angular velocity: identity rotation
+    pr, Minv, f_ext = make_problem(ctx, sc)
+    prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=10, tol=0.0, cfm=0.01)
+    pr.step(5e-3, 0.2, prm)
+    v6 = pr.velocity()
+    pr.advance(5e-3)
+    pos, R, v, w = pr.state()
+    v6_old = np.concatenate([sc["v"], sc["w"]], axis=1)
+    po, Ro = orc.position_update(sc["p"], sc["R"], v6_old, v6, 5e-3)
+    assert np.abs(pos - po).max() <= 1e-15 and np.abs(R - Ro).max() <= 1e-15
+    assert np.array_equal(v, v6[:, :3]) and np.array_equal(w, v6[:, 3:])
+    pr.close()
