@@ -26,6 +26,7 @@ EXPORTS = [
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
     "egs_problem_advance", "egs_problem_get_state",
     "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
+    "egs_update_contacts",
 ]
 
 
@@ -133,6 +134,18 @@ class Context:
                                            _p(body1), _p(J0), _p(J1), _p(is_eq), _p(lo), _p(hi), _p(rhs),
                                            C.byref(prm), C.c_int32(precision), _p(x), C.byref(st)))
         return x, st
+
+    def update_contacts(self, pos, R, side=None, max_contacts=None):
+        """Ensemble::UpdateContacts + contact pruning on the GPU (reference order)."""
+        pos, R = _f64(pos), _f64(R)
+        n = pos.reshape(-1, 3).shape[0]
+        side = _f64(np.tile([0.3, 0.3, 0.3], (n, 1)) if side is None else side)
+        cap = int(max_contacts if max_contacts is not None else 64 * n + 64)
+        b0 = np.zeros(cap, np.int32); b1 = np.zeros(cap, np.int32); data = np.zeros((cap, 7))
+        m = C.c_int32(0)
+        self.check(load().egs_update_contacts(self.h, C.c_int32(n), _p(pos), _p(R), _p(side), C.c_int32(cap),
+                                              C.byref(m), _p(b0), _p(b1), _p(data)))
+        return b0[:m.value].copy(), b1[:m.value].copy(), data[:m.value].copy()
 
     def mixed_constraints_solve(self, A, b, Ceq, lo, hi, use_bounds=0):
         A, b, lo, hi = map(_f64, (A, b, lo, hi))

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/eggshell_amd.h"
+#include "collide.h"
 #include "dense_lcp.h"
 #include "kernels.h"
 #include "plan.h"
@@ -723,6 +724,19 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
     if (ok) *ok = good ? 1 : 0;
     if (pivots) *pivots = piv;
     if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "MixedConstraintsSolver did not reach a solution" : msg);
+    return EGS_OK;
+  });
+}
+
+egs_status egs_update_contacts(egs_context *ctx, int32_t n, const double *pos, const double *R, const double *side,
+                               int32_t max_contacts, int32_t *m_out, int32_t *body0, int32_t *body1, double *data) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (n < 0 || !m_out || (n > 0 && (!pos || !R || !side)) || (max_contacts > 0 && (!body0 || !body1 || !data)))
+    return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  *m_out = 0;
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    *m_out = update_contacts(ctx->stream, n, pos, R, side, max_contacts, body0, body1, data, nullptr, nullptr);
     return EGS_OK;
   });
 }

@@ -1,0 +1,494 @@
+// collide.hip -- contact generation on the GPU: Ensemble::UpdateContacts
+// (ensembles.cc:445-480) + the contact-vs-contact pruning of
+// CheckAndCorrectEnsembleState (ensembles.cc:241-329), i.e. the step that feeds
+// the constraint solve.
+//
+//   box-ground   collision.cc:408-436   (8 vertices, z < 0)
+//   box-box      collision.cc:166-388   (15-axis SAT, face clipping, edge-edge)
+//
+// The contact LIST ORDER is part of the result (the solver sweeps in list
+// order): all ground contacts by body, then body pairs i < j lexicographically,
+// each pair's contacts in the order the reference emits them.  The GPU keeps it
+// with counts + exclusive scans instead of push_back:
+//   1. ground_count / cand_kernel     per body: ground contacts; candidate j > i
+//      (bounding spheres overlap; ordered by wave ballot)
+//   2. flatten candidates (scan)      -> pair list in (i, j) order
+//   3. narrow_kernel<false>           per pair: SAT + clipping, count kept contacts
+//   4. scan, narrow_kernel<true> + ground emit  -> final arrays
+// Arithmetic follows oracle/collision.c operation by operation (fp64,
+// -ffp-contract=off), so the contact set is bit-identical to the CPU oracle's.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "collide.h"
+
+namespace egs {
+
+namespace {
+
+constexpr int KMAX = 64;      // candidate partners j > i per body
+constexpr int MAXC = 16;      // contacts per pair before pruning
+
+struct HipErr : std::runtime_error { using std::runtime_error::runtime_error; };
+void chk(hipError_t e, const char *what) {
+  if (e != hipSuccess) throw HipErr(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(call) chk((call), #call)
+
+template <typename T>
+struct Buf {
+  T *p = nullptr;
+  explicit Buf(size_t n) { if (n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T))); }
+  ~Buf() { if (p) (void)hipFree(p); }
+  Buf(const Buf &) = delete;
+  Buf &operator=(const Buf &) = delete;
+};
+
+struct Box { double c[3]; double R[9]; double h[3]; };
+struct V2 { double x, y; };
+
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *o) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ void mat3_vec(const double *A, const double *v, double *o) {
+  double x = (A[0] * v[0] + A[1] * v[1]) + A[2] * v[2];
+  double y = (A[3] * v[0] + A[4] * v[1]) + A[5] * v[2];
+  double z = (A[6] * v[0] + A[7] * v[1]) + A[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *O) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_T(const double *A, double *O) {
+  O[0] = A[0]; O[1] = A[3]; O[2] = A[6]; O[3] = A[1]; O[4] = A[4]; O[5] = A[7]; O[6] = A[2]; O[7] = A[5]; O[8] = A[8];
+}
+__device__ __forceinline__ void colv(const double *R, int j, double *o) { o[0] = R[j]; o[1] = R[3 + j]; o[2] = R[6 + j]; }
+__device__ __forceinline__ double sgn(double a) { return (a >= 0) ? 1.0 : -1.0; }
+
+// collision.cc:408-436; returns the count, optionally writes [<=8][7]
+__device__ int ground_contacts(const double *c, const double *R, const double *side, double *out) {
+  int n = 0;
+  double c0[3], c1[3], c2[3];
+  colv(R, 0, c0); colv(R, 1, c1); colv(R, 2, c2);
+  for (int x = -1; x <= 1; x += 2)
+    for (int y = -1; y <= 1; y += 2)
+      for (int z = -1; z <= 1; z += 2) {
+        double v[3];
+        for (int k = 0; k < 3; ++k)
+          v[k] = ((c[k] + c0[k] * side[0] * 0.5 * x) + c1[k] * side[1] * 0.5 * y) + c2[k] * side[2] * 0.5 * z;
+        if (v[2] < 0) {
+          if (out) {
+            double *o = out + 7 * n;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = 0; o[4] = 0; o[5] = 1; o[6] = -v[2];
+          }
+          ++n;
+        }
+      }
+  return n;
+}
+
+__device__ void line_closest_approach(const double *pa, const double *ua, const double *pb, const double *ub,
+                                      double *alpha, double *beta) {  // collision.cc:53-69
+  double p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  double uaub = dot3(ua, ub), q1 = dot3(ua, p), q2 = -dot3(ub, p);
+  double d = 1 - uaub * uaub;
+  if (d == 0) { *alpha = 0; *beta = 0; }
+  else { *alpha = (q1 + uaub * q2) / d; *beta = (uaub * q1 + q2) / d; }
+}
+
+__device__ int seg_line(V2 p1, V2 p2, V2 nrm, double d, V2 *p) {  // collision.cc:77-87
+  double k1 = (nrm.x * p1.x + nrm.y * p1.y) + d;
+  double k2 = (nrm.x * p2.x + nrm.y * p2.y) + d;
+  if (k1 * k2 < 0) {
+    double t = k1 / (k2 - k1);
+    p->x = p1.x - t * (p2.x - p1.x);
+    p->y = p1.y - t * (p2.y - p1.y);
+    return 1;
+  }
+  return 0;
+}
+
+__device__ int clip_poly(const V2 *poly, int n, V2 nrm, double d, V2 *out) {  // collision.cc:91-106
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((nrm.x * poly[i].x + nrm.y * poly[i].y) + d >= 0) out[k++] = poly[i];
+    V2 np;
+    if (seg_line(poly[i], poly[(i + 1) % n], nrm, d, &np)) out[k++] = np;
+  }
+  return k;
+}
+
+__device__ int box_rect(const Box *B, const Box *Rc, V2 *poly) {  // collision.cc:112-164
+  const double kTol = 1e-9;
+  double Bc[3] = {B->c[0] - Rc->c[0], B->c[1] - Rc->c[1], B->c[2] - Rc->c[2]};
+  int n = 4;
+  poly[0] = V2{-Rc->h[0], -Rc->h[1]};
+  poly[1] = V2{-Rc->h[0], Rc->h[1]};
+  poly[2] = V2{Rc->h[0], Rc->h[1]};
+  poly[3] = V2{Rc->h[0], -Rc->h[1]};
+  V2 tmp[24];
+  double Rn[3], r0[3], r1[3];
+  colv(Rc->R, 2, Rn); colv(Rc->R, 0, r0); colv(Rc->R, 1, r1);
+  for (int i = 0; i < 3; ++i) {
+    double Bn[3], cr[3];
+    colv(B->R, i, Bn);
+    double BnBc = dot3(Bn, Bc);
+    cross3(Bn, Rn, cr);
+    double crossn = sqrt(dot3(cr, cr));
+    for (int j = -1; j <= 1; j += 2) {
+      double Bd = -j * BnBc - B->h[i];
+      if (crossn < kTol) {
+        if (Bd <= 0) continue;
+        return 0;
+      }
+      V2 H = {dot3(r0, Bn), dot3(r1, Bn)};
+      V2 Hn = {-j * H.x, -j * H.y};
+      int k = clip_poly(poly, n, Hn, -Bd, tmp);
+      for (int q = 0; q < k; ++q) poly[q] = tmp[q];
+      n = k;
+      if (n == 0) return 0;
+    }
+  }
+  return n;
+}
+
+// collision.cc:166-388.  contacts [<= MAXC][7]; returns the number generated.
+__device__ int collide_boxes(const double *c1, const double *R1, const double *s1, const double *c2,
+                             const double *R2, const double *s2, double *contacts) {
+  const double kAlign = 0.9962, kTol = 1e-9;
+  Box box1, box2;
+  for (int k = 0; k < 3; ++k) { box1.c[k] = c1[k]; box2.c[k] = c2[k]; box1.h[k] = s1[k] * 0.5; box2.h[k] = s2[k] * 0.5; }
+  for (int k = 0; k < 9; ++k) { box1.R[k] = R1[k]; box2.R[k] = R2[k]; }
+  double R1t[9], R[9], Q[9], p[3], dc[3];
+  mat3_T(R1, R1t);
+  mat3_mul(R1t, R2, R);
+  for (int k = 0; k < 3; ++k) dc[k] = c2[k] - c1[k];
+  mat3_vec(R1t, dc, p);
+  for (int k = 0; k < 9; ++k) Q[k] = fabs(R[k]);
+  int aacount = 0;
+  for (int j = 0; j < 3; ++j) {
+    double mx = Q[j];
+    if (Q[3 + j] > mx) mx = Q[3 + j];
+    if (Q[6 + j] > mx) mx = Q[6 + j];
+    aacount += (mx > kAlign);
+  }
+  const double *H1 = box1.h, *H2 = box2.h;
+  double min_FN = -DBL_MAX, sep_FN[3] = {0, 0, 0};
+  int code_FN = 0;
+#define RR(i, j) R[3 * (i) + (j)]
+#define QQ(i, j) Q[3 * (i) + (j)]
+#define SEPF(e1expr, e2expr, Rsrc, col, thecode)                                  \
+  {                                                                               \
+    double e1 = (e1expr);                                                         \
+    double separation = fabs(e1) - (e2expr);                                      \
+    if (separation > 0) return 0;                                                 \
+    if (separation > min_FN) {                                                    \
+      min_FN = separation;                                                        \
+      double nn[3]; colv(Rsrc, col, nn);                                          \
+      double sg = sgn(e1);                                                        \
+      sep_FN[0] = sg * nn[0]; sep_FN[1] = sg * nn[1]; sep_FN[2] = sg * nn[2];      \
+      code_FN = (thecode);                                                        \
+    }                                                                             \
+  }
+  SEPF(p[0], H1[0] + ((H2[0] * QQ(0, 0) + H2[1] * QQ(0, 1)) + H2[2] * QQ(0, 2)), R1, 0, 1)
+  SEPF(p[1], H1[1] + ((H2[0] * QQ(1, 0) + H2[1] * QQ(1, 1)) + H2[2] * QQ(1, 2)), R1, 1, 2)
+  SEPF(p[2], H1[2] + ((H2[0] * QQ(2, 0) + H2[1] * QQ(2, 1)) + H2[2] * QQ(2, 2)), R1, 2, 3)
+  SEPF((RR(0, 0) * p[0] + RR(1, 0) * p[1]) + RR(2, 0) * p[2], ((H1[0] * QQ(0, 0) + H1[1] * QQ(1, 0)) + H1[2] * QQ(2, 0)) + H2[0], R2, 0, 4)
+  SEPF((RR(0, 1) * p[0] + RR(1, 1) * p[1]) + RR(2, 1) * p[2], ((H1[0] * QQ(0, 1) + H1[1] * QQ(1, 1)) + H1[2] * QQ(2, 1)) + H2[1], R2, 1, 5)
+  SEPF((RR(0, 2) * p[0] + RR(1, 2) * p[1]) + RR(2, 2) * p[2], ((H1[0] * QQ(0, 2) + H1[1] * QQ(1, 2)) + H1[2] * QQ(2, 2)) + H2[2], R2, 2, 6)
+#undef SEPF
+  double min_EE = -DBL_MAX, sep_EE[3] = {0, 0, 0};
+  int code_EE = 0;
+#define SEPE(e1expr, e2expr, n0, n1, n2, thecode)                                 \
+  {                                                                               \
+    double nv[3] = {(n0), (n1), (n2)};                                            \
+    double len = sqrt(dot3(nv, nv));                                              \
+    if (len > kTol) {                                                             \
+      double e1 = (e1expr);                                                       \
+      double separation = fabs(e1) - (e2expr);                                    \
+      if (separation > 0) return 0;                                               \
+      separation /= len;                                                          \
+      if (separation > min_EE) {                                                  \
+        min_EE = separation;                                                      \
+        double dn = sgn(e1) * len;                                                \
+        sep_EE[0] = nv[0] / dn; sep_EE[1] = nv[1] / dn; sep_EE[2] = nv[2] / dn;    \
+        code_EE = (thecode);                                                      \
+      }                                                                           \
+    }                                                                             \
+  }
+  SEPE(p[2] * RR(1, 0) - p[1] * RR(2, 0), (H1[1] * QQ(2, 0) + H1[2] * QQ(1, 0) + H2[1] * QQ(0, 2) + H2[2] * QQ(0, 1)), 0, -RR(2, 0), RR(1, 0), 7)
+  SEPE(p[2] * RR(1, 1) - p[1] * RR(2, 1), (H1[1] * QQ(2, 1) + H1[2] * QQ(1, 1) + H2[0] * QQ(0, 2) + H2[2] * QQ(0, 0)), 0, -RR(2, 1), RR(1, 1), 8)
+  SEPE(p[2] * RR(1, 2) - p[1] * RR(2, 2), (H1[1] * QQ(2, 2) + H1[2] * QQ(1, 2) + H2[0] * QQ(0, 1) + H2[1] * QQ(0, 0)), 0, -RR(2, 2), RR(1, 2), 9)
+  SEPE(p[0] * RR(2, 0) - p[2] * RR(0, 0), (H1[0] * QQ(2, 0) + H1[2] * QQ(0, 0) + H2[1] * QQ(1, 2) + H2[2] * QQ(1, 1)), RR(2, 0), 0, -RR(0, 0), 10)
+  SEPE(p[0] * RR(2, 1) - p[2] * RR(0, 1), (H1[0] * QQ(2, 1) + H1[2] * QQ(0, 1) + H2[0] * QQ(1, 2) + H2[2] * QQ(1, 0)), RR(2, 1), 0, -RR(0, 1), 11)
+  SEPE(p[0] * RR(2, 2) - p[2] * RR(0, 2), (H1[0] * QQ(2, 2) + H1[2] * QQ(0, 2) + H2[0] * QQ(1, 1) + H2[1] * QQ(1, 0)), RR(2, 2), 0, -RR(0, 2), 12)
+  SEPE(p[1] * RR(0, 0) - p[0] * RR(1, 0), (H1[0] * QQ(1, 0) + H1[1] * QQ(0, 0) + H2[1] * QQ(2, 2) + H2[2] * QQ(2, 1)), -RR(1, 0), RR(0, 0), 0, 13)
+  SEPE(p[1] * RR(0, 1) - p[0] * RR(1, 1), (H1[0] * QQ(1, 1) + H1[1] * QQ(0, 1) + H2[0] * QQ(2, 2) + H2[2] * QQ(2, 0)), -RR(1, 1), RR(0, 1), 0, 14)
+  SEPE(p[1] * RR(0, 2) - p[0] * RR(1, 2), (H1[0] * QQ(1, 2) + H1[1] * QQ(0, 2) + H2[0] * QQ(2, 1) + H2[1] * QQ(2, 0)), -RR(1, 2), RR(0, 2), 0, 15)
+#undef SEPE
+#undef RR
+#undef QQ
+  {
+    double t[3];
+    mat3_vec(R1, sep_EE, t);
+    sep_EE[0] = t[0]; sep_EE[1] = t[1]; sep_EE[2] = t[2];
+  }
+  const int best_FN = (code_EE == 0) ? 1 : (min_FN > min_EE);
+  int n = 0;
+  if (aacount == 0 && !best_FN) {  // edge-edge, collision.cc:278-301
+    double pa[3], pb[3];
+    for (int k = 0; k < 3; ++k) { pa[k] = c1[k]; pb[k] = c2[k]; }
+    for (int j = 0; j < 3; ++j) {
+      double a1[3], a2[3];
+      colv(R1, j, a1); colv(R2, j, a2);
+      double sa = sgn(dot3(sep_EE, a1)), sb = sgn(dot3(sep_EE, a2));
+      for (int k = 0; k < 3; ++k) { pa[k] += sa * H1[j] * a1[k]; pb[k] -= sb * H2[j] * a2[k]; }
+    }
+    double ua[3], ub[3], alpha, beta;
+    colv(R1, (code_EE - 7) / 3, ua);
+    colv(R2, (code_EE - 7) % 3, ub);
+    line_closest_approach(pa, ua, pb, ub, &alpha, &beta);
+    for (int k = 0; k < 3; ++k) {
+      contacts[k] = (pa[k] + ua[k] * alpha + pb[k] + ub[k] * beta) * 0.5;
+      contacts[3 + k] = sep_EE[k];
+    }
+    contacts[6] = -min_EE;
+    return 1;
+  }
+  const Box *A = (code_FN <= 3) ? &box1 : &box2;
+  Box B = (code_FN <= 3) ? box2 : box1;
+  const double sgnA = (code_FN <= 3) ? 1.0 : -1.0;
+  double An[3] = {sep_FN[0] * sgnA, sep_FN[1] * sgnA, sep_FN[2] * sgnA};
+  double BRt[9], nf[3];
+  mat3_T(B.R, BRt);
+  mat3_vec(BRt, An, nf);
+  int nfi = 0;
+  {
+    double best = fabs(nf[0]);
+    if (fabs(nf[1]) > best) { best = fabs(nf[1]); nfi = 1; }
+    if (fabs(nf[2]) > best) { best = fabs(nf[2]); nfi = 2; }
+  }
+  double Bn[3], bcol[3];
+  colv(B.R, nfi, bcol);
+  for (int k = 0; k < 3; ++k) Bn[k] = -sgn(nf[nfi]) * bcol[k];
+  {
+    double BR[9], a0[3], a1[3], a2[3];
+    for (int k = 0; k < 3; ++k) B.c[k] += Bn[k] * B.h[nfi];
+    colv(B.R, (nfi + 1) % 3, a0); colv(B.R, (nfi + 2) % 3, a1); colv(B.R, nfi, a2);
+    for (int k = 0; k < 3; ++k) { BR[3 * k] = a0[k]; BR[3 * k + 1] = a1[k]; BR[3 * k + 2] = a2[k]; }
+    const double h0 = B.h[(nfi + 1) % 3], h1 = B.h[(nfi + 2) % 3];
+    for (int k = 0; k < 9; ++k) B.R[k] = BR[k];
+    B.h[0] = h0; B.h[1] = h1; B.h[2] = 0;
+  }
+  double Afc[3];
+  for (int k = 0; k < 3; ++k) Afc[k] = A->c[k] + An[k] * A->h[(code_FN - 1) % 3];
+  const double Ad = -dot3(An, Afc);
+  V2 poly[24];
+  const int np = box_rect(A, &B, poly);
+  double b0[3], b1[3];
+  colv(B.R, 0, b0); colv(B.R, 1, b1);
+  for (int i = 0; i < np && n < MAXC; ++i) {
+    double pos[3];
+    for (int k = 0; k < 3; ++k) pos[k] = (B.c[k] + b0[k] * poly[i].x) + b1[k] * poly[i].y;
+    const double depth = -(dot3(An, pos) + Ad);
+    if (fabs(depth) > kTol || aacount >= 2) {
+      double *o = contacts + 7 * n++;
+      for (int k = 0; k < 3; ++k) { o[k] = pos[k]; o[3 + k] = sep_FN[k]; }
+      o[6] = depth;
+    }
+  }
+  if (n == 0) {  // collision.cc:378-386
+    for (int k = 0; k < 3; ++k) { contacts[k] = c2[k]; contacts[3 + k] = sep_FN[k]; }
+    contacts[6] = -min_FN;
+    n = 1;
+  }
+  return n;
+}
+
+// ---- kernels ---------------------------------------------------------------
+__global__ void __launch_bounds__(256) ground_kernel(int n, const double *pos, const double *R, const double *side,
+                                                     const int *off, int *count, int *b0, int *b1, double *data) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  double buf[8 * 7];
+  const int c = ground_contacts(pos + 3 * (size_t)b, R + 9 * (size_t)b, side + 3 * (size_t)b, off ? buf : nullptr);
+  if (!off) { count[b] = c; return; }
+  for (int k = 0; k < c; ++k) {
+    const size_t o = (size_t)off[b] + k;
+    b0[o] = -1; b1[o] = b;  // contact.h:13-15: ground contacts are (null, body)
+    for (int q = 0; q < 7; ++q) data[o * 7 + q] = buf[7 * k + q];
+  }
+}
+
+// One wavefront per body i: candidates j > i whose bounding spheres overlap, in
+// ascending j (ballot keeps the order).
+__global__ void __launch_bounds__(64) cand_kernel(int n, const double *pos, const double *side, int *cand, int *count,
+                                                  int *overflow) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const double ci[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+  const double ri = 0.5 * sqrt(dot3(side + 3 * (size_t)i, side + 3 * (size_t)i));
+  int found = 0;
+  for (int base = i + 1; base < n; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    if (j < n) {
+      const double d[3] = {pos[3 * (size_t)j] - ci[0], pos[3 * (size_t)j + 1] - ci[1], pos[3 * (size_t)j + 2] - ci[2]};
+      const double rj = 0.5 * sqrt(dot3(side + 3 * (size_t)j, side + 3 * (size_t)j));
+      const double rr = (ri + rj) * 1.0000001 + 1e-12;  // conservative: never drops a touching pair
+      hit = dot3(d, d) <= rr * rr;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      const int k = found + __popcll(mask & ((1ull << lane) - 1ull));
+      if (k < KMAX) cand[(size_t)i * KMAX + k] = j;
+    }
+    found += __popcll(mask);
+  }
+  if (lane == 0) {
+    if (found > KMAX) { atomicOr(overflow, 1); found = KMAX; }
+    count[i] = found;
+  }
+}
+
+__global__ void __launch_bounds__(256) flatten_kernel(int n, const int *cand, const int *count, const int *off, int *pi,
+                                                      int *pj) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < count[i]; ++k) { pi[off[i] + k] = i; pj[off[i] + k] = cand[(size_t)i * KMAX + k]; }
+}
+
+// Narrow phase + contact-vs-contact pruning within the pair
+// (ensembles.cc:308-316, kMinConstraintDistance = 1e-6: a contact is deleted if
+// ANY earlier contact of the same pair lies within 1e-6 of it).
+template <bool EMIT>
+__global__ void __launch_bounds__(64) narrow_kernel(int npairs, const int *pi, const int *pj, const double *pos,
+                                                    const double *R, const double *side, const int *off, int base,
+                                                    int *count, int *b0, int *b1, double *data) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= npairs) return;
+  const int i = pi[t], j = pj[t];
+  double cs[MAXC * 7];
+  const int nc = collide_boxes(pos + 3 * (size_t)i, R + 9 * (size_t)i, side + 3 * (size_t)i, pos + 3 * (size_t)j,
+                               R + 9 * (size_t)j, side + 3 * (size_t)j, cs);
+  int kept = 0;
+  for (int a = 0; a < nc; ++a) {
+    bool del = false;
+    for (int b = 0; b < a; ++b) {
+      const double d[3] = {cs[7 * b] - cs[7 * a], cs[7 * b + 1] - cs[7 * a + 1], cs[7 * b + 2] - cs[7 * a + 2]};
+      if (sqrt(dot3(d, d)) < 1e-6) del = true;
+    }
+    if (del) continue;
+    if (EMIT) {
+      const size_t o = (size_t)base + off[t] + kept;
+      b0[o] = i; b1[o] = j;
+      for (int q = 0; q < 7; ++q) data[o * 7 + q] = cs[7 * a + q];
+    }
+    ++kept;
+  }
+  if (!EMIT) count[t] = kept;
+}
+
+// ---- exclusive scan (int32), three small kernels ----------------------------
+constexpr int SCAN_CHUNK = 2048;  // elements per block (256 threads x 8)
+__global__ void __launch_bounds__(256) scan_reduce_kernel(int n, const int *in, int *block_sums) {
+  __shared__ int red[256];
+  const int base = blockIdx.x * SCAN_CHUNK;
+  int s = 0;
+  for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) if (base + k < n) s += in[base + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+__global__ void scan_blocks_kernel(int nblocks, int *block_sums, int *total) {  // one thread: nblocks is small
+  int run = 0;
+  for (int b = 0; b < nblocks; ++b) { const int v = block_sums[b]; block_sums[b] = run; run += v; }
+  *total = run;
+}
+__global__ void __launch_bounds__(256) scan_apply_kernel(int n, const int *in, const int *block_sums, int *out) {
+  __shared__ int part[256];
+  const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+  int v[8], s = 0;
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = block_sums[blockIdx.x]; for (int t = 0; t < 256; ++t) { const int x = part[t]; part[t] = run; run += x; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+int exclusive_scan(hipStream_t s, int n, const int *in, int *out, int *scratch_blocks, int *total_d) {
+  const int nblocks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1), 0, s, nblocks, scratch_blocks, total_d);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks, out);
+  int total = 0;
+  HIPCHK(hipMemcpyAsync(&total, total_d, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return total;
+}
+
+}  // namespace
+
+int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
+                    int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs) {
+  if (n_ground) *n_ground = 0;
+  if (n_pairs) *n_pairs = 0;
+  if (n <= 0) return 0;
+  const size_t nn = (size_t)n;
+  Buf<double> dpos(nn * 3), dR(nn * 9), dside(nn * 3);
+  Buf<int> gcount(nn), goff(nn), ccount(nn), coff(nn), cand(nn * KMAX), flags(2);
+  Buf<int> blocks((nn * 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1024);
+  HIPCHK(hipMemcpyAsync(dpos.p, pos, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dR.p, R, nn * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dside.p, side, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
+  const int gb = (n + 255) / 256;
+  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos.p, dR.p, dside.p, (const int *)nullptr, gcount.p,
+                     (int *)nullptr, (int *)nullptr, (double *)nullptr);
+  const int G = exclusive_scan(s, n, gcount.p, goff.p, blocks.p, flags.p + 1);
+  hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos.p, dside.p, cand.p, ccount.p, flags.p);
+  const int C = exclusive_scan(s, n, ccount.p, coff.p, blocks.p, flags.p + 1);
+  int overflow = 0;
+  HIPCHK(hipMemcpyAsync(&overflow, flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (overflow) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
+  Buf<int> pi((size_t)C), pj((size_t)C), pcount((size_t)C), poff((size_t)C), blocks2(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
+  int P = 0;
+  if (C > 0) {
+    hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, cand.p, ccount.p, coff.p, pi.p, pj.p);
+    hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, pi.p, pj.p, dpos.p, dR.p, dside.p,
+                       (const int *)nullptr, 0, pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr);
+    P = exclusive_scan(s, C, pcount.p, poff.p, blocks2.p, flags.p + 1);
+  }
+  const int m = G + P;
+  if (n_ground) *n_ground = G;
+  if (n_pairs) *n_pairs = C;
+  if (m > max_contacts) throw std::invalid_argument("update_contacts: max_contacts too small (" + std::to_string(m) + " needed)");
+  if (m == 0) return 0;
+  Buf<int> db0((size_t)m), db1((size_t)m);
+  Buf<double> ddata((size_t)m * 7);
+  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos.p, dR.p, dside.p, goff.p, (int *)nullptr, db0.p,
+                     db1.p, ddata.p);
+  if (C > 0)
+    hipLaunchKernelGGL((narrow_kernel<true>), dim3((C + 63) / 64), dim3(64), 0, s, C, pi.p, pj.p, dpos.p, dR.p, dside.p,
+                       poff.p, G, (int *)nullptr, db0.p, db1.p, ddata.p);
+  HIPCHK(hipMemcpyAsync(body0, db0.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(body1, db1.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(data, ddata.p, (size_t)m * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  return m;
+}
+
+}  // namespace egs

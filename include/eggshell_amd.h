@@ -180,6 +180,20 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N,
                                        double *x, double *w, int32_t *ok,
                                        int32_t *pivots);
 
+/* ---- contact generation ("next" row 1): replaces Ensemble::UpdateContacts
+ *      (ensembles.cc:445-480 -> CollideBoxAndGround collision.cc:408-436,
+ *      CollideBoxes collision.cc:166-388) and the contact-vs-contact pruning of
+ *      CheckAndCorrectEnsembleState (ensembles.cc:308-328, 1e-6).
+ * pos [n][3], R [n][9], side_lengths [n][3] -> the contact list in the
+ * reference's order (ground contacts by body, then body pairs i < j):
+ * body0/body1 [m] (-1 = ground), data [m][7] = position, normal, depth, ready
+ * for egs_problem_set_constraints with kind = EGS_CONTACT_BOX.             */
+egs_status egs_update_contacts(egs_context *ctx, int32_t n_bodies,
+                               const double *pos, const double *R,
+                               const double *side_lengths, int32_t max_contacts,
+                               int32_t *m_out, int32_t *body0, int32_t *body1,
+                               double *data);
+
 /* ---- diagnostics (host only, needs no GPU) -------------------------------
  * The schedule the solver derives from the constraint graph: islands, the
  * workgroup tile each constraint lands in (-1 = cross-workgroup path) and the
