@@ -14,8 +14,8 @@ static void print_vec(const char *name, const VectorXd &v) {
   std::printf("\n");
 }
 
-// An axis-aligned box pile with the contact list UpdateContacts would produce
-// (ensembles.cc:445-480; analytic here, collision is a "next" row).
+// An axis-aligned box pile; its contacts come from Ensemble::UpdateContacts
+// (device collision), called by Step() as in the reference (ensembles.cc:393).
 class BoxPile : public Ensemble {
  public:
   BoxPile(int nx, int ny, int nz, double sink = 1e-3, double gap = 1e-2) {
@@ -29,39 +29,9 @@ class BoxPile : public Ensemble {
           Vector3d p(ix * (side + gap), iy * (side + gap), (h - sink) + k * (side - sink));
           components_.push_back(std::make_shared<Body>(p, Vector3d::Zero(), 1.0, Matrix3d::Identity(), Vector3d::Zero(), I));
         }
-    ncol_ = ncol; nz_ = nz;
   }
-  // What UpdateContacts would find (the reference calls it from Step, after
-  // Init: contacts are not part of the initial-condition check).
-  void MakeContacts() {
-    const double side = 0.3, h = 0.15;
-    const int ncol = ncol_, nz = nz_;
-    ContactsList cs;
-    for (int b = 0; b < ncol; ++b)
-      for (int sx = -1; sx <= 1; sx += 2)
-        for (int sy = -1; sy <= 1; sy += 2) {
-          const Vector3d &p = components_[b]->p();
-          Vector3d v(p[0] + side * 0.5 * sx, p[1] + side * 0.5 * sy, p[2] + side * 0.5 * -1);
-          cs.push_back(std::make_shared<Contact>(components_[b], b, ContactGeometry(v, Vector3d(0, 0, 1), -v[2])));
-        }
-    for (int k = 0; k + 1 < nz; ++k)
-      for (int c = 0; c < ncol; ++c) {
-        const int i = k * ncol + c, j = (k + 1) * ncol + c;
-        const Vector3d &pi = components_[i]->p(), &pj = components_[j]->p();
-        const double zb = pj[2] + (-1.0) * h, ztop = pi[2] + h;
-        const double px[4] = {-h, -h, h, h}, py[4] = {-h, h, h, -h};
-        for (int q = 0; q < 4; ++q) {
-          Vector3d pos(pj[0] + px[q], pj[1] + py[q], zb);
-          cs.push_back(std::make_shared<Contact>(components_[i], i, components_[j], j,
-                                                 ContactGeometry(pos, Vector3d(0, 0, 1), -(pos[2] + -ztop))));
-        }
-      }
-    SetContacts(cs);
-  }
-
- private:
-  int ncol_ = 0, nz_ = 0;
 };
+
 
 int main(int argc, char **argv) {
   try {
@@ -88,13 +58,33 @@ int main(int argc, char **argv) {
 
     BoxPile pile(2, 2, 3);
     pile.Init();
-    pile.MakeContacts();
     pile.solver_params.method = EGS_GAUSS_SEIDEL;
     pile.solver_params.max_iters = 50;
     pile.solver_params.tol = 0.0;
     pile.Step(0.005);
     print_vec("pile_lambda", pile.last_lambda);
     print_vec("pile_v", pile.GetVelocities());
+    {
+      // A small drop test: the full Ensemble::Step loop (UpdateContacts on the
+      // GPU, projected SOR on the GPU, midpoint positions) as model.cc:78-95
+      // drives the reference's cairn, dt = 5e-3 (model.cc:80).
+      BoxPile drop(1, 1, 3, /*sink=*/-0.05, /*gap=*/0.0);   // three boxes, 5 cm apart, 5 cm above ground
+      drop.Init();
+      drop.solver_params.method = EGS_SOR;
+      drop.solver_params.max_iters = 500;
+      drop.solver_params.tol = 1e-9;
+      int contacts_seen = 0;
+      for (int s = 0; s < 120; ++s) {
+        drop.Step(0.005);
+        contacts_seen += (int)drop.constraints().size();
+      }
+      VectorXd dp(9);
+      for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) dp(3 * i + k) = drop.components()[i]->p()[k];
+      print_vec("drop_p", dp);
+      print_vec("drop_v", drop.GetVelocities());
+      std::printf("drop_contacts %d\n", contacts_seen);
+    }
     if (argc > 1 && !std::strcmp(argv[1], "--dense")) {
       // Lcp::MixedConstraintsSolver on the reference's literal 5x5 (lcp.cc:369-376)
       const double a[25] = {2.1104, 1.4090, 1.5055, 1.3060, 1.1413, 1.4090, 1.9846, 1.7126, 1.0858, 1.9358, 1.5055, 1.7126, 2.1673,

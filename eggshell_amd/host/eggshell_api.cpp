@@ -316,11 +316,11 @@ VectorXd Ensemble::StepVelocities_ODE(double dt, const VectorXd &v, double erp) 
   prm.cfm = cfm_coeff;
   VectorXd v_new(n_ * 6);
   if (describable) {
-    if (topology_dirty_ || !problem_) {
+    if (!problem_ || b0 != plan_b0_ || b1 != plan_b1_) {  // re-plan only when the contact topology changed
       if (problem_) egs_problem_destroy(problem_);
       problem_ = nullptr;
       egs::check(egs_problem_create(egs::DefaultContext(), n_, m, b0.data(), b1.data(), EGS_F64, &problem_));
-      topology_dirty_ = false;
+      plan_b0_ = b0; plan_b1_ = b1;
     }
     std::vector<double> pos((size_t)n_ * 3), R((size_t)n_ * 9), vl((size_t)n_ * 3), w((size_t)n_ * 3), Minv((size_t)n_ * 36);
     for (int i = 0; i < n_; ++i) {
@@ -393,10 +393,34 @@ void Ensemble::StepPositions_ODE(double dt, const VectorXd &v, const VectorXd &v
   }
 }
 
+void Ensemble::UpdateContacts() {  // ensembles.cc:445-480 (+ :308-328)
+  contacts_.clear();
+  if (n_ == 0) return;
+  std::vector<double> pos((size_t)n_ * 3), R((size_t)n_ * 9), side((size_t)n_ * 3);
+  for (int i = 0; i < n_; ++i) {
+    const Vector3d sl = components_[i]->GetSideLengths();
+    for (int k = 0; k < 3; ++k) { pos[3 * i + k] = components_[i]->p()[k]; side[3 * i + k] = sl[k]; }
+    for (int k = 0; k < 9; ++k) R[9 * i + k] = components_[i]->R().d[k];
+  }
+  const int cap = 64 * n_ + 64;
+  std::vector<int32_t> b0(cap), b1(cap);
+  std::vector<double> data((size_t)cap * 7);
+  int32_t m = 0;
+  egs::check(egs_update_contacts(egs::DefaultContext(), n_, pos.data(), R.data(), side.data(), cap, &m, b0.data(),
+                                 b1.data(), data.data()));
+  for (int k = 0; k < m; ++k) {
+    const double *d = &data[(size_t)k * 7];
+    ContactGeometry cg(Vector3d(d[0], d[1], d[2]), Vector3d(d[3], d[4], d[5]), d[6]);
+    if (b0[k] < 0) contacts_.push_back(std::make_shared<Contact>(components_[b1[k]], b1[k], cg));
+    else contacts_.push_back(std::make_shared<Contact>(components_[b0[k]], b0[k], components_[b1[k]], b1[k], cg));
+  }
+}
+
 void Ensemble::Step(double dt, Integrator g) {  // ensembles.cc:390-427
   if (g != Integrator::OPEN_DYNAMICS_ENGINE)
     throw egs::Error(EGS_ERR_UNSUPPORTED, "only Integrator::OPEN_DYNAMICS_ENGINE is on the accelerated path");
   const VectorXd v = GetVelocities();
+  if (detect_contacts) UpdateContacts();
   VectorXd v_new = StepVelocities_ODE(dt, v);
   StepPositions_ODE(dt, v, v_new);
 }

@@ -170,7 +170,12 @@ class Ensemble {  // ensembles.h:25-186
   const MatrixXd &M_inverse() const { return M_inverse_; }
   const ConstraintsList constraints() const { return CombineConstraintsLists(); }
   const ComponentsList &components() const { return components_; }
-  void SetContacts(const ContactsList &c) { contacts_ = c; topology_dirty_ = true; }
+  void SetContacts(const ContactsList &c) { contacts_ = c; }
+  // Find all contacts between Bodies or between Body and ground, clear and
+  // update contacts_ (ensembles.cc:445-480), then drop contacts closer than
+  // 1e-6 to an earlier contact of the same pair (ensembles.cc:308-328): on the GPU.
+  void UpdateContacts();
+  bool detect_contacts = true;   // Step() calls UpdateContacts() as the reference does (ensembles.cc:393)
   const VectorXd GetVelocities() const;                                  // ensembles.cc:429-436
   VectorXd ComputePositionConstraintError() const;                       // ensembles.cc:156-171
   // solver parameters (compile-time constants in the reference)
@@ -195,7 +200,7 @@ class Ensemble {  // ensembles.h:25-186
   VectorXd StepVelocities_ODE(double dt, const VectorXd &v, double error_reduction_param = 0.2);  // :563-575
   void StepPositions_ODE(double dt, const VectorXd &v, const VectorXd &v_new);                    // :577-591
   egs_problem *problem_ = nullptr;
-  bool topology_dirty_ = true;
+  std::vector<int32_t> plan_b0_, plan_b1_;   // topology the cached device problem was planned for
 };
 
 class Chain : public Ensemble {  // ensembles.h:188-198, ensembles.cc:668-707
