@@ -720,7 +720,8 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
     HIPCHK(hipSetDevice(ctx->device));
     int piv = 0;
     std::string msg;
-    const bool good = dense_mixed_constraints(ctx->stream, N, A, b, C, lo, hi, use_bounds != 0, x, w, &piv, &msg);
+    const bool good = dense_mixed_constraints(ctx->stream, N, A, b, C, lo, hi, (use_bounds & 1) != 0,
+                                              (use_bounds & 2) != 0, x, w, &piv, &msg);
     if (ok) *ok = good ? 1 : 0;
     if (pivots) *pivots = piv;
     if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "MixedConstraintsSolver did not reach a solution" : msg);

@@ -334,15 +334,22 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail) {
 
 // Murty on (A n x n device, b device).  Mirrors lcp.cc:157-274; box_fix as in
 // the oracle (true box problem: solve once before the first check).
+//
+// block = true is NOT the reference's pivot rule: block principal pivoting
+// (Judice & Pires): every infeasible index flips at once while the number of
+// infeasibilities keeps falling, with single-index steps (largest index) as the
+// safeguard that guarantees termination.  Same unique solution for SPD A, in
+// tens of factorisations instead of hundreds -- and no min(1000, 2^n) cap, which
+// the reference's single-index rule exhausts for n >~ 600.
 bool murty_device(hipStream_t s, int n, const double *dA, const double *db, const std::vector<double> &lo,
-                  const std::vector<double> &hi, bool box_fix, double *dx, double *dw, int *pivots_out,
+                  const std::vector<double> &hi, bool box_fix, bool block, double *dx, double *dw, int *pivots_out,
                   std::string *msg) {
   for (int i = 0; i < n; ++i)
     if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
   *pivots_out = 0;
   if (n == 0) return true;
   const double p2 = std::pow(2.0, n);
-  const int max_iterations = p2 > 1000 ? 1000 : (int)p2;  // lcp.cc:168
+  const int max_iterations = block ? 4 * n + 100 : (p2 > 1000 ? 1000 : (int)p2);  // lcp.cc:168
   const int npad_max = (n + NB - 1) / NB * NB;
   Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max);
   Buf<uint8_t> S_d(n);
@@ -381,8 +388,9 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   };
   upload_state();
   MurtyRecord rc;
-  std::vector<double> xh(n);
+  std::vector<double> xh(n), wh(n);
   int iter = 0, pivots = 0;
+  int best_ninf = n + 1, patience = 10;   // block rule state
   bool force = box_fix, solved = false;
   {  // goodness of the start iterate for the best-solution memory
     check(dx, dw, r.p, &rc);
@@ -394,6 +402,28 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
       if (rc.first_offender == 0x7fffffff) {
         // no index to flip but not a solution (residual / sign checks failed):
         // the reference recomputes with unchanged S; do the same.
+      } else if (block) {
+        HIPCHK(hipMemcpyAsync(xh.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(wh.data(), dw, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> bad;
+        for (int i = 0; i < n; ++i) {
+          const bool off = S[i] ? (xh[i] < lo[i] || xh[i] > hi[i])
+                                : ((Cv[i] == lo[i] && wh[i] < 0) || (Cv[i] == hi[i] && wh[i] > 0));
+          if (off) bad.push_back(i);
+        }
+        const int ninf = (int)bad.size();
+        bool all = true;
+        if (ninf < best_ninf) { best_ninf = ninf; patience = 10; }
+        else if (patience > 0) --patience;
+        else all = false;
+        auto flip = [&](int i) {
+          if (S[i]) { S[i] = 0; Cv[i] = (xh[i] < lo[i]) ? lo[i] : hi[i]; }
+          else S[i] = 1;
+        };
+        if (all) for (int i : bad) flip(i);
+        else flip(bad.back());
+        upload_state();
       } else {
         if (S[rc.first_offender]) HIPCHK(hipMemcpyAsync(xh.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost, s)), HIPCHK(hipStreamSynchronize(s));
         apply_flip(rc, xh);
@@ -448,7 +478,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   if (fail) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
   if (solved) return true;  // x, w hold the solution iterate (== best, see lcp.cc:241)
   // capped: return the best-seen iterate and re-check it with the looser 1e-8 (lcp.cc:241-246)
-  if (!box_fix) {
+  if (!box_fix && !block) {
     HIPCHK(hipMemcpyAsync(dx, bx.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(dw, bw.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
@@ -462,7 +492,8 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
 }  // namespace
 
 bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double *b, const uint8_t *C, const double *lo,
-                             const double *hi, bool use_bounds, double *x, double *w, int *pivots, std::string *msg) {
+                             const double *hi, bool use_bounds, bool block_pivoting, double *x, double *w, int *pivots,
+                             std::string *msg) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
   double amax = 0, asym = 0;
@@ -496,7 +527,7 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   std::vector<double> l2(ni), h2(ni);
   for (int k = 0; k < ni; ++k) { l2[k] = use_bounds ? lo[I[k]] : 0.0; h2[k] = use_bounds ? hi[I[k]] : std::numeric_limits<double>::infinity(); }
   int piv = 0;
-  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, xi.p, wi.p, &piv, msg);
+  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, xi.p, wi.p, &piv, msg);
   if (pivots) *pivots = piv;
   if (!ok) return false;
   // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)

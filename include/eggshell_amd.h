@@ -171,8 +171,13 @@ egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats);
 /* ---- entry 3: replaces Lcp::MixedConstraintsSolver(A, b, C, x_lo, x_hi, x, w)
  *      lcp.h:21-23 / lcp.cc:276-336 (and Lcp::MurtyPrincipalPivot,
  *      lcp.cc:157-274).  A [N][N], b, C, lo, hi [N] -> x, w [N]; *ok as the
- *      reference's bool.  use_bounds = 0 reproduces the reference (bounds
- *      ignored, quirk Q3); 1 solves the true box problem.                    */
+ *      reference's bool.  use_bounds is a bit mask:
+ *        0      the reference: bounds ignored (quirk Q3), single-index pivots,
+ *               cap min(1000, 2^n) pivots (lcp.cc:168)
+ *        bit 0  honour x_lo/x_hi (the true box problem)
+ *        bit 1  block principal pivoting instead of the single-index rule: same
+ *               solution, tens of factorisations instead of hundreds, no cap --
+ *               the reference's rule cannot finish N >~ 1200 mixed problems.    */
 egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N,
                                        const double *A, const double *b,
                                        const uint8_t *C, const double *lo,

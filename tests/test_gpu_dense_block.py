@@ -1,0 +1,54 @@
+"""GPU (-m gpu): block principal pivoting (use_bounds bit 1) -- NOT the
+reference's pivot rule, same LCP solution.  Checked against the reference-rule
+oracle where that finishes, and by KKT conditions at BASELINE C5 size
+(N = 2048), which the reference's own rule cannot finish (1000-pivot cap,
+lcp.cc:168)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_oracle_lcp import _spd
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+
+
+@pytest.mark.parametrize("dim", [5, 50, 130, 300])
+def test_block_rule_same_solution_as_reference_rule(ctx, dim):
+    rng = np.random.default_rng(dim)
+    A = _spd(rng, dim)
+    b = rng.uniform(-1, 1, dim)
+    Ceq = rng.integers(0, 2, dim).astype(np.uint8)
+    lo, hi = np.zeros(dim), np.full(dim, INF)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, Ceq, lo, hi, use_bounds=2)
+    oko, xo, wo, pivo = orc.mixed_constraints(A, b, Ceq, lo, hi)
+    assert ok and oko
+    assert piv <= max(pivo, 3)
+    scale = max(1.0, np.abs(xo).max())
+    assert np.abs(x - xo).max() <= 1e-8 * scale and np.abs(w - wo).max() <= 1e-8 * scale
+    # box variant
+    A2 = A + 0.5 * np.eye(dim)
+    b2 = rng.uniform(-3, 3, dim)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A2, b2, Ceq, np.full(dim, -0.3), np.full(dim, 0.4), use_bounds=3)
+    oko, xo, wo, _ = orc.mixed_constraints(A2, b2, Ceq, np.full(dim, -0.3), np.full(dim, 0.4), use_bounds=1)
+    assert ok and oko and np.abs(x - xo).max() <= 1e-8
+
+
+def test_config5_n2048(ctx):
+    """BASELINE C5: N = 2048, A = M^T M + 1e-3 I, b ~ U(-1,1), C ~ Bernoulli(1/2),
+    seed 0.  The reference rule hits its 1000-pivot cap here (reported false);
+    the block rule solves it: Ax = b + w, w = 0 on equality rows, x >= 0, w >= 0,
+    x.w = 0 on inequality rows."""
+    rng = np.random.default_rng(0)
+    N = 2048
+    M = rng.uniform(-1, 1, (N, N))
+    A = M.T @ M + 1e-3 * np.eye(N)
+    b = rng.uniform(-1, 1, N)
+    Ceq = rng.integers(0, 2, N).astype(np.uint8)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, Ceq, np.zeros(N), np.full(N, INF), use_bounds=2)
+    assert ok and piv < 200
+    eq = Ceq.astype(bool)
+    assert np.linalg.norm(A @ x - b - w) <= 1e-6 * np.linalg.norm(A @ x)
+    assert not w[eq].any()
+    assert (x[~eq] >= 0).all() and (w[~eq] >= -1e-7).all()
+    assert np.abs(x[~eq] * w[~eq]).max() < 1e-7

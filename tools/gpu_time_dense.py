@@ -29,3 +29,9 @@ for N in (256, 512, 1024, 2048):
         tc = time.perf_counter() - t
         line += f" | CPU oracle ok={oko} pivots={pivo} {tc*1e3:.0f} ms, speedup {tc/tg:.1f}x, max|dx|={np.abs(x-xo).max():.1e}"
     print(line, flush=True)
+    t = time.perf_counter()
+    ok2, x2, w2, piv2 = ctx.mixed_constraints_solve(A, b, Ceq, lo, hi, use_bounds=2)
+    tb = time.perf_counter() - t
+    res2 = np.linalg.norm(A @ x2 - b - w2) if ok2 else float('nan')
+    extra = f" max|x-x_ref_rule|={np.abs(x2-x).max():.1e}" if ok else ""
+    print(f"      block principal pivoting: ok={ok2} factorisations={piv2} {tb*1e3:.1f} ms |Ax-b-w|={res2:.2e}{extra}", flush=True)

@@ -1,0 +1,30 @@
+"""PCIe-inclusive rate of entry 1 (host buffers in, host lambda out): the one-shot
+egs_solve_blocks on C3, including plan + allocation + upload + solve + download.
+Never bench.py's `value`; quoted in DESIGN.md."""
+import os, sys, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
+from eggshell_amd import capi, scenes
+from helpers import system_from_scene, ode_rhs_from_scene
+ctx = capi.Context(0)
+sc = scenes.box_stack(16, 16, 16)
+s, err = system_from_scene(sc)
+rhs, _ = ode_rhs_from_scene(sc, s, err, 5e-3)
+prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=100, tol=0.0, cfm=0.01)
+for _ in range(3): ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, prm)
+t = time.perf_counter(); N = 20
+for _ in range(N): x, st = ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, prm)
+dt = (time.perf_counter() - t) / N
+print(f"one-shot egs_solve_blocks C3: {dt*1e3:.2f} ms per call = {1/dt:.0f} calls/s (plan+alloc+H2D 6.2 MB+solve+D2H)")
+pr = capi.Problem(ctx, s.n, s.body0, s.body1)
+t = time.perf_counter()
+for _ in range(N):
+    pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs); pr.solve(prm, want_stats=False); x = pr.lambda_()
+dt = (time.perf_counter() - t) / N
+print(f"resident problem, re-upload blocks + solve + download: {dt*1e3:.2f} ms per call = {1/dt:.0f} calls/s")
+b0, b1, d = ctx.update_contacts(sc['p'], sc['R'])
+t = time.perf_counter()
+for _ in range(N): ctx.update_contacts(sc['p'], sc['R'])
+dt = (time.perf_counter() - t) / N
+print(f"egs_update_contacts C3 (4096 bodies -> {len(b0)} contacts, host in/out): {dt*1e3:.2f} ms per call")
