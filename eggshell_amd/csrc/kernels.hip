@@ -705,9 +705,9 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleArgs A) {
 // body accumulators and tickets live in global memory and the lanes of a
 // persistent grid (<= one 256-thread workgroup per CU, so every workgroup is
 // resident) each own a strided slice of the constraint list.  Hand-off between
-// workgroups follows the agent-scope release/acquire recipe: payload stores ->
-// release fence -> s_waitcnt vmcnt(0) -> relaxed ticket store; relaxed ticket
-// poll -> acquire fence -> payload loads.  Every wait is bounded.
+// workgroups: sc1 (write-through) payload stores -> s_waitcnt vmcnt(0) -> sc1
+// ticket store; sc1 ticket poll -> sc1 payload loads, all by the same lane.
+// Every wait is bounded.
 template <typename T>
 __device__ __forceinline__ T gld(const T *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -811,7 +811,11 @@ __global__ void __launch_bounds__(256) global_solve_kernel(const GlobalArgs<REAL
       const unsigned t1 = has1 ? gld(A.tickets + d.body1) : want1;
       ready = (t0 == want0) && (t1 == want1);
       if (ready) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // Every hand-off byte is stored sc1 (write-through, gst) and loaded sc1
+        // (L1-bypassing, gld), and the storing lane drains vmcnt before it bumps
+        // the ticket, so no L1 invalidate / L2 write-back is needed (guide G16,
+        // "sc1 both sides"); the wavefront-scope fence only pins compiler order.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         REAL a0[6], a1[6], dx[3];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -842,7 +846,7 @@ __global__ void __launch_bounds__(256) global_solve_kernel(const GlobalArgs<REAL
 #pragma unroll
           for (int q = 0; q < 6; ++q) gst(A.acc + (size_t)d.body1 * 6 + q, a1[q]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (has0) gst(A.tickets + d.body0, want0 + 1u);
         if (has1) gst(A.tickets + d.body1, want1 + 1u);
