@@ -35,7 +35,8 @@ namespace {
 
 constexpr size_t kEventPairs = 4096;
 constexpr uint32_t kSpinLimit = 1u << 22;
-constexpr int kQuadMaxConstraints = 32768;  // above this the 1-lane tiles fill the GPU better
+constexpr int kQuadMaxConstraints = 32768;
+constexpr int kMaxPatchTiles = 512;          // 2 resident 256-thread workgroups per CU at 232 VGPRs  // above this the 1-lane tiles fill the GPU better
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -87,11 +88,15 @@ struct egs_problem {
   // used for GS/SOR when the problem is small and every island fits a tile
   Plan planq;
   bool use_quad = false;
+  bool patch_enabled = true;   // EGS_PATCH=0 forces the all-global path for oversize islands
   DevBuf<LaneDesc> q_lanes;
   DevBuf<int32_t> q_tile_nslots, q_tile_slot_off, q_slot_body;
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
   DevBuf<GlobalDesc> gcons;
   DevBuf<uint32_t> gtickets;
+  // oversize islands as body patches (GS/SOR): LDS for private bodies, global for shared
+  DevBuf<LaneDesc> p_lanes;
+  DevBuf<int32_t> p_tile_nslots, p_tile_slot_off, p_slot_body;
   // topology + state (fp64)
   DevBuf<int32_t> body0, body1, kind;
   DevBuf<double> pos, R, v, w, Minv_d, f_ext, data, err, v6, res_partials;
@@ -176,7 +181,11 @@ template <typename REAL>
 void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweeps, int resume) {
   egs_context *ctx = p->ctx;
   const bool quad = p->use_quad && method != EGS_JACOBI;
+  const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 &&
+                     p->plan.n_patch_tiles <= kMaxPatchTiles && p->patch_enabled;
   record_kernel_event(ctx, true);
+  if (patch && !resume)  // shared bodies accumulate in global memory from zero
+    HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * sizeof(REAL), ctx->stream));
   if (quad || p->plan.n_tiles > 0) {
     SolveArgs<REAL> a;
     a.lanes = quad ? p->q_lanes.p : p->lanes.p;
@@ -210,7 +219,29 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
     }
   }
-  if (!quad && !p->plan.global.empty()) {
+  if (patch) {
+    SolveArgs<REAL> a;
+    a.lanes = p->p_lanes.p; a.tile_nslots = p->p_tile_nslots.p; a.tile_slot_off = p->p_tile_slot_off.p;
+    a.slot_body = p->p_slot_body.p;
+    a.wsB0 = a.wsB1 = a.wsD = a.wsInv = nullptr;
+    a.body0 = p->body0.p; a.body1 = p->body1.p; a.m = p->m;
+    a.Minv = reinterpret_cast<const REAL *>(p->Minv_r.p);
+    a.J0 = reinterpret_cast<const REAL *>(p->J0.p); a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
+    a.is_eq = p->is_eq.p;
+    a.lo = reinterpret_cast<const REAL *>(p->lo.p); a.hi = reinterpret_cast<const REAL *>(p->hi.p);
+    a.rhs = reinterpret_cast<const REAL *>(p->rhs.p);
+    a.x = reinterpret_cast<REAL *>(p->x.p); a.acc = reinterpret_cast<REAL *>(p->acc.p);
+    a.wres = reinterpret_cast<REAL *>(p->wres.p);
+    a.error_flag = p->error_flag.p;
+    a.cfm = cfm; a.kscale = kscale; a.sweeps = sweeps; a.resume = resume;
+    a.max_slots = p->plan.patch_max_slots; a.spin_limit = kSpinLimit;
+    HIPCHK(hipMemsetAsync(p->gtickets.p, 0, sizeof(uint32_t) * (size_t)(p->n > 0 ? p->n : 1), ctx->stream));
+    launch_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
+    GlobalArgs<REAL> g{};
+    g.cons = p->gcons.p; g.mg = (int)p->plan.global.size();
+    g.J0 = a.J0; g.J1 = a.J1; g.rhs = a.rhs; g.x = a.x; g.acc = a.acc; g.wres = a.wres; g.cfm = cfm;
+    launch_global_wres<REAL>(g, ctx->stream);
+  } else if (!quad && !p->plan.global.empty()) {
     GlobalArgs<REAL> g;
     g.cons = p->gcons.p;
     g.mg = (int)p->plan.global.size();
@@ -485,6 +516,14 @@ egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int3
     p->slot_body.alloc(pl.slot_body.size()); upload(p->slot_body, pl.slot_body.data(), pl.slot_body.size(), s);
     p->gcons.alloc(pl.global.size()); upload(p->gcons, pl.global.data(), pl.global.size(), s);
     p->gtickets.alloc((size_t)(n > 0 ? n : 1));
+    if (pl.n_patch_tiles > 0) {
+      p->p_lanes.alloc(pl.patch_lanes.size()); upload(p->p_lanes, pl.patch_lanes.data(), pl.patch_lanes.size(), s);
+      p->p_tile_nslots.alloc(pl.patch_tile_nslots.size()); upload(p->p_tile_nslots, pl.patch_tile_nslots.data(), pl.patch_tile_nslots.size(), s);
+      p->p_tile_slot_off.alloc(pl.patch_tile_slot_off.size()); upload(p->p_tile_slot_off, pl.patch_tile_slot_off.data(), pl.patch_tile_slot_off.size(), s);
+      p->p_slot_body.alloc(pl.patch_slot_body.size()); upload(p->p_slot_body, pl.patch_slot_body.data(), pl.patch_slot_body.size(), s);
+      const char *pe = std::getenv("EGS_PATCH");
+      p->patch_enabled = !(pe && std::atoi(pe) == 0);
+    }
     {  // quad schedule: small problems whose islands all fit 64-constraint tiles
       const char *env = std::getenv("EGS_QUAD");
       const int force = env ? std::atoi(env) : -1;

@@ -67,6 +67,13 @@ void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
 template <typename REAL>
 void launch_global_solve(const GlobalArgs<REAL> &a, hipStream_t s);
+// w = A x - rhs for the constraints of a GlobalDesc list (after the last sweep)
+template <typename REAL>
+void launch_global_wres(const GlobalArgs<REAL> &a, hipStream_t s);
+// oversize islands cut into body patches (plan.h): LDS for private bodies,
+// global sc1 hand-off for shared ones
+template <typename REAL>
+void launch_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s);
 // latency-optimised variant: 4 lanes per constraint, 64 constraints per tile
 template <typename REAL>
 void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s);

@@ -25,6 +25,106 @@ struct UnionFind {
 };
 }  // namespace
 
+namespace {
+// Cut the oversize islands into patches (see plan.h).  On any obstacle (a body
+// owning more constraints than a tile holds, 16-bit overflow) the patch plan is
+// left empty and the caller uses the all-global path.
+void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t *body1,
+                   const std::vector<int32_t> &cnt, const std::vector<int32_t> &pos0,
+                   const std::vector<int32_t> &pos1) {
+  const int block = plan.block;
+  const int mg = (int)plan.global.size();
+  // owner body of a constraint = its first real body
+  auto owner = [&](int c) { return body0[c] >= 0 ? body0[c] : body1[c]; };
+  std::vector<int32_t> owned(n_bodies, 0);
+  std::vector<std::vector<int32_t>> touch(n_bodies);   // body -> global-list positions of its constraints
+  std::vector<char> in_big(n_bodies, 0);
+  for (int g = 0; g < mg; ++g) {
+    const int c = plan.global[g].cidx;
+    if (owner(c) < 0) return;                  // world-world constraint in an oversize island: cannot happen
+    ++owned[owner(c)];
+    for (int b : {body0[c], body1[c]})
+      if (b >= 0) { touch[b].push_back(g); in_big[b] = 1; if (cnt[b] > 65535) return; }
+  }
+  for (int b = 0; b < n_bodies; ++b) if (owned[b] > block) return;
+  // BFS-grown patches, seeds in ascending body index
+  std::vector<int32_t> patch_of(n_bodies, -1);
+  std::vector<int32_t> patch_fill;
+  std::vector<int32_t> queue;
+  for (int seed = 0; seed < n_bodies; ++seed) {
+    if (!in_big[seed] || patch_of[seed] >= 0) continue;
+    const int pid = (int)patch_fill.size();
+    patch_fill.push_back(0);
+    queue.clear();
+    queue.push_back(seed);
+    for (size_t qh = 0; qh < queue.size(); ++qh) {
+      const int b = queue[qh];
+      if (patch_of[b] >= 0) continue;
+      if (patch_fill[pid] + owned[b] > block) continue;   // does not fit: left for a later patch
+      patch_of[b] = pid;
+      patch_fill[pid] += owned[b];
+      for (int g : touch[b]) {
+        const int c = plan.global[g].cidx;
+        for (int nb : {body0[c], body1[c]})
+          if (nb >= 0 && patch_of[nb] < 0) queue.push_back(nb);
+      }
+      if (patch_fill[pid] == block) break;
+    }
+  }
+  // drop empty patches (bodies that own nothing) by renumbering patches with constraints
+  const int np_all = (int)patch_fill.size();
+  std::vector<int32_t> renum(np_all, -1);
+  int np = 0;
+  for (int p = 0; p < np_all; ++p) if (patch_fill[p] > 0) renum[p] = np++;
+  // tile of a constraint = patch of its owner; body is shared if touched from >1 tile
+  std::vector<int32_t> first_tile(n_bodies, -1);
+  std::vector<char> shared(n_bodies, 0);
+  for (int g = 0; g < mg; ++g) {
+    const int c = plan.global[g].cidx;
+    const int t = renum[patch_of[owner(c)]];
+    for (int b : {body0[c], body1[c]}) {
+      if (b < 0) continue;
+      if (first_tile[b] < 0) first_tile[b] = t;
+      else if (first_tile[b] != t) shared[b] = 1;
+    }
+  }
+  LaneDesc idle{};
+  idle.cidx = -1;
+  plan.n_patch_tiles = np;
+  plan.patch_lanes.assign((size_t)np * block, idle);
+  plan.patch_tile_nslots.assign(np, 1);
+  plan.patch_tile_slot_off.assign(np, 0);
+  std::vector<int32_t> fill(np, 0), slot_of(n_bodies, -1);
+  std::vector<std::vector<int32_t>> tile_bodies(np);
+  for (int g = 0; g < mg; ++g) {              // list order -> lanes ascending by list index
+    const int c = plan.global[g].cidx;
+    const int t = renum[patch_of[owner(c)]];
+    auto slot = [&](int b) -> uint16_t {
+      if (b < 0) return 0;
+      if (shared[b]) return kSharedSlot;
+      if (slot_of[b] < 0) { slot_of[b] = plan.patch_tile_nslots[t]++; tile_bodies[t].push_back(b); }
+      return (uint16_t)slot_of[b];
+    };
+    LaneDesc d;
+    d.cidx = c;
+    d.slot0 = slot(body0[c]);
+    d.slot1 = slot(body1[c]);
+    d.pos0 = (uint16_t)pos0[c]; d.cnt0 = (uint16_t)(body0[c] >= 0 ? cnt[body0[c]] : 0);
+    d.pos1 = (uint16_t)pos1[c]; d.cnt1 = (uint16_t)(body1[c] >= 0 ? cnt[body1[c]] : 0);
+    plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
+  }
+  int off = 0;
+  for (int t = 0; t < np; ++t) {
+    plan.patch_tile_slot_off[t] = off;
+    plan.patch_slot_body.push_back(-1);
+    for (int b : tile_bodies[t]) plan.patch_slot_body.push_back(b);
+    off += plan.patch_tile_nslots[t];
+    plan.patch_max_slots = std::max(plan.patch_max_slots, plan.patch_tile_nslots[t]);
+  }
+  for (int b = 0; b < n_bodies; ++b) plan.n_shared_bodies += shared[b];
+}
+}  // namespace
+
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
                 int block) {
   if (n_bodies < 0 || m < 0 || block <= 0 || block > 1024)
@@ -149,6 +249,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     g.pos1 = pos1[i]; g.cnt1 = body1[i] >= 0 ? cnt[body1[i]] : 0;
     plan.global.push_back(g);
   }
+  if (!plan.global.empty()) build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1);
   return plan;
 }
 

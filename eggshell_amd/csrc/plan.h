@@ -41,7 +41,18 @@ struct Plan {
   std::vector<int32_t> tile_slot_off; // per tile, offset into slot_body
   std::vector<int32_t> slot_body;     // slot -> global body index (-1 for slot 0)
   std::vector<GlobalDesc> global;     // constraints of oversize islands, list order
+  // Oversize islands cut into workgroup-sized PATCHES of bodies (BFS-grown):
+  // a patch tile owns the constraints whose first body lies in the patch.  A
+  // body touched by one patch only keeps its accumulator/ticket in that
+  // workgroup's LDS (slot >= 1); a body touched by several patches is SHARED:
+  // slot == kSharedSlot, accumulator/ticket in global memory.
+  int n_patch_tiles = 0, patch_max_slots = 1;
+  std::vector<LaneDesc> patch_lanes;        // n_patch_tiles * block
+  std::vector<int32_t> patch_tile_nslots, patch_tile_slot_off, patch_slot_body;
+  int n_shared_bodies = 0;
 };
+
+constexpr uint16_t kSharedSlot = 0xFFFF;
 
 // Throws std::invalid_argument on out-of-range body indices.
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,

@@ -1,0 +1,270 @@
+// solve_device.h -- device helpers shared by the solve kernels (kernels.hip,
+// patch_solve.hip): the oracle-ordered arithmetic (oracle/pgs_fast.inc), the
+// per-constraint register block, and the hand-placed LDS / global hand-offs.
+// Everything lives in an anonymous namespace: one private copy per translation unit.
+#pragma once
+#include "kernels.h"
+
+namespace egs {
+namespace {
+
+template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
+template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T dot6(const T *j, const T *a) {
+  T s = j[0] * a[0];
+  s = tfma(j[1], a[1], s);
+  s = tfma(j[2], a[2], s);
+  s = tfma(j[3], a[3], s);
+  s = tfma(j[4], a[4], s);
+  s = tfma(j[5], a[5], s);
+  return s;
+}
+
+// three-term chain over one half (linear or angular) of a 3x6 row
+template <typename T>
+__device__ __forceinline__ T dot3h(const T *j, const T *a) {
+  T s = j[0] * a[0];
+  s = tfma(j[1], a[1], s);
+  s = tfma(j[2], a[2], s);
+  return s;
+}
+// (A x)_row without cfm: (p0 + p1) + (p2 + p3), oracle row_dot
+template <typename T>
+__device__ __forceinline__ T row_dot(const T *j0, const T *a0, const T *j1, const T *a1) {
+  const T p0 = dot3h(j0, a0), p1 = dot3h(j0 + 3, a0 + 3);
+  const T p2 = dot3h(j1, a1), p3 = dot3h(j1 + 3, a1 + 3);
+  return (p0 + p1) + (p2 + p3);
+}
+
+// sparse_iterations_utils.cc:12-21, branch-free: same result for every input
+// (NaN compares false and passes through, as in the reference).
+template <typename T>
+__device__ __forceinline__ T project(T x, bool eq, T lo, T hi) {
+  T r = x;
+  r = (x > hi) ? hi : r;
+  r = (x < lo) ? lo : r;
+  return eq ? x : r;
+}
+
+// a += B d, rows applied in order 0,1,2 (oracle acc_add)
+template <typename T>
+__device__ __forceinline__ void acc_add(T *a, const T *B, const T *d) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    T t = tfma(B[3 * c + 0], d[0], a[c]);
+    t = tfma(B[3 * c + 1], d[1], t);
+    t = tfma(B[3 * c + 2], d[2], t);
+    a[c] = t;
+  }
+}
+
+__device__ __forceinline__ unsigned lds_load_acquire(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Per-lane constants of one constraint, held in registers for all sweeps.
+template <typename REAL>
+struct Cons {
+  REAL J0[18], J1[18];  // 3x6 row-major, zero for a world side
+  REAL B0[18], B1[18];  // (W J^T) as 6x3 row-major
+  REAL D[9];            // J0 B0 + J1 B1
+  REAL inv[3];          // 1 / ((D_rr + cfm) * kscale)
+  REAL rhs[3], lo[3], hi[3];
+  bool eq[3];
+};
+
+template <typename REAL>
+__device__ __forceinline__ void load_cons(const SolveArgs<REAL> &A, int cidx, bool has0, bool has1,
+                                          int body0, int body1, Cons<REAL> &c) {
+#pragma unroll
+  for (int k = 0; k < 18; ++k) {
+    c.J0[k] = has0 ? A.J0[(size_t)cidx * 18 + k] : REAL(0);
+    c.J1[k] = has1 ? A.J1[(size_t)cidx * 18 + k] : REAL(0);
+  }
+#pragma unroll
+  for (int k = 0; k < 18; ++k) { c.B0[k] = REAL(0); c.B1[k] = REAL(0); }
+  if (has0) {
+    const REAL *W = A.Minv + (size_t)body0 * 36;
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      REAL Wr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) c.B0[3 * cc + r] = dot6(Wr, c.J0 + 6 * r);
+    }
+  }
+  if (has1) {
+    const REAL *W = A.Minv + (size_t)body1 * 36;
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      REAL Wr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) c.B1[3 * cc + r] = dot6(Wr, c.J1 + 6 * r);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      REAL d0 = c.J0[6 * r] * c.B0[q];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) d0 = tfma(c.J0[6 * r + k], c.B0[3 * k + q], d0);
+      REAL d1 = c.J1[6 * r] * c.B1[q];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) d1 = tfma(c.J1[6 * r + k], c.B1[3 * k + q], d1);
+      c.D[3 * r + q] = d0 + d1;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    c.inv[r] = REAL(1) / ((c.D[4 * r] + A.cfm) * A.kscale);
+    c.rhs[r] = A.rhs[(size_t)cidx * 3 + r];
+    c.lo[r] = A.lo[(size_t)cidx * 3 + r];
+    c.hi[r] = A.hi[(size_t)cidx * 3 + r];
+    c.eq[r] = A.is_eq[(size_t)cidx * 3 + r] != 0;
+  }
+}
+
+// res_r = rhs_r - (J_r . a + cfm x_r)
+template <typename REAL>
+__device__ __forceinline__ void row_residuals(const Cons<REAL> &c, const REAL *a0, const REAL *a1,
+                                              const REAL *x, REAL cfm, REAL *res) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    REAL full = tfma(cfm, x[r], row_dot(c.J0 + 6 * r, a0, c.J1 + 6 * r, a1));
+    res[r] = c.rhs[r] - full;
+  }
+}
+
+// One projected update of the 3 rows of a constraint; returns dx.
+template <typename REAL, int METHOD>
+__device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res, REAL *x, REAL *dx) {
+  if (METHOD == 0) {  // Jacobi: no intra-block coupling
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      REAL xn = project(tfma(res[r], c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      dx[r] = xn - x[r];
+      x[r] = xn;
+    }
+  } else if (METHOD == 1) {  // forward
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      REAL t = res[r];
+#pragma unroll
+      for (int l = 0; l < r; ++l) t = tfma(-c.D[3 * r + l], dx[l], t);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      dx[r] = xn - x[r];
+      x[r] = xn;
+    }
+  } else {  // backward
+#pragma unroll
+    for (int r = 2; r >= 0; --r) {
+      REAL t = res[r];
+#pragma unroll
+      for (int l = 2; l > r; --l) t = tfma(-c.D[3 * r + l], dx[l], t);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      dx[r] = xn - x[r];
+      x[r] = xn;
+    }
+  }
+}
+
+template <typename REAL>
+__device__ __forceinline__ void lds_load6(const REAL *p, REAL *a) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a[k] = p[k];
+}
+template <typename REAL>
+__device__ __forceinline__ void lds_store6(REAL *p, const REAL *a) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p[k] = a[k];
+}
+
+
+// ---- ordered LDS hand-off, hand-placed (see quad_solve.hip) ------------------
+// DS instructions of a wavefront execute in issue order: both ticket loads, then
+// the accumulator loads, ONE wait; stores of the accumulators, then the tickets.
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
+                                       unsigned &t1, double (&a0)[6], double (&a1)[6]) {
+  d2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b32 %0, %8\n\t"
+      "ds_read_b32 %1, %9\n\t"
+      "ds_read_b128 %2, %10\n\t"
+      "ds_read_b128 %3, %10 offset:16\n\t"
+      "ds_read_b128 %4, %10 offset:32\n\t"
+      "ds_read_b128 %5, %11\n\t"
+      "ds_read_b128 %6, %11 offset:16\n\t"
+      "ds_read_b128 %7, %11 offset:32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
+      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
+      : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
+__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
+                                       unsigned &t1, float (&a0)[6], float (&a1)[6]) {
+  f2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b32 %0, %8\n\t"
+      "ds_read_b32 %1, %9\n\t"
+      "ds_read_b64 %2, %10\n\t"
+      "ds_read_b64 %3, %10 offset:8\n\t"
+      "ds_read_b64 %4, %10 offset:16\n\t"
+      "ds_read_b64 %5, %11\n\t"
+      "ds_read_b64 %6, %11 offset:8\n\t"
+      "ds_read_b64 %7, %11 offset:16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
+      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
+      : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
+__device__ __forceinline__ void store6(unsigned ac, const double (&a)[6]) {
+  d2_t u0 = {a[0], a[1]}, u1 = {a[2], a[3]}, u2 = {a[4], a[5]};
+  asm volatile(
+      "ds_write_b128 %0, %1\n\t"
+      "ds_write_b128 %0, %2 offset:16\n\t"
+      "ds_write_b128 %0, %3 offset:32"
+      :: "v"(ac), "v"(u0), "v"(u1), "v"(u2) : "memory");
+}
+__device__ __forceinline__ void store6(unsigned ac, const float (&a)[6]) {
+  f2_t u0 = {a[0], a[1]}, u1 = {a[2], a[3]}, u2 = {a[4], a[5]};
+  asm volatile(
+      "ds_write_b64 %0, %1\n\t"
+      "ds_write_b64 %0, %2 offset:8\n\t"
+      "ds_write_b64 %0, %3 offset:16"
+      :: "v"(ac), "v"(u0), "v"(u1), "v"(u2) : "memory");
+}
+__device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"(tick_addr), "v"(v) : "memory");
+}
+
+
+template <typename T>
+__device__ __forceinline__ T gld(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void gst(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+}  // namespace
+}  // namespace egs

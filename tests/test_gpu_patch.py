@@ -1,0 +1,47 @@
+"""GPU (-m gpu): oversize islands as body patches (LDS for private bodies, global
+hand-off for shared ones) vs the all-global path (EGS_PATCH=0) vs the oracle:
+identical bits; tol-terminated runs (resume launches) included."""
+import numpy as np
+import pytest
+
+from eggshell_amd import capi, scenes
+from helpers import random_system, system_from_scene
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(ctx, s, rhs, cfm, method, K, tol=0.0):
+    pr = capi.Problem(ctx, s.n, s.body0, s.body1)
+    pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+    st = pr.solve(capi.params(method=method, max_iters=K, tol=tol, cfm=cfm))
+    x, a = pr.lambda_(), pr.accumulators()
+    pr.close()
+    return x, a, st
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_patch_and_global_paths_agree(ctx, method, monkeypatch):
+    rng = np.random.default_rng(60)
+    wall = scenes.brick_wall(20, 14)
+    b0, b1, data = ctx.update_contacts(wall["p"], wall["R"])
+    wall.update(kind=np.ones(len(b0), np.int32), body0=b0, body1=b1, data=data)
+    cases = [system_from_scene(wall)[0],
+             system_from_scene(scenes.concat([scenes.chain(900), scenes.box_stack(3, 3, 3), scenes.chain(300)]))[0],
+             random_system(rng, 300, 2500, connected=True)[0]]
+    for s in cases:
+        rhs = rng.uniform(-1, 1, 3 * s.m)
+        for K in (0, 1, 7, 30):
+            xf, af, _, rf = orc.fast_iterate(s, rhs, 0.05, method, max_iters=K, tol=0.0)
+            for patch in ("1", "0"):
+                monkeypatch.setenv("EGS_PATCH", patch)
+                x, a, st = solve(ctx, s, rhs, 0.05, method, K)
+                assert st.status == capi.OK and st.n_global > 256
+                assert np.array_equal(x, xf) and np.array_equal(a, af), (patch, K)
+                assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+    monkeypatch.setenv("EGS_PATCH", "1")
+    s = cases[1]
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    x, a, st = solve(ctx, s, rhs, 0.5, method, 500, tol=1e-9)
+    xf, af, it, rf = orc.fast_iterate(s, rhs, 0.5, method, max_iters=500, tol=1e-9)
+    assert st.iterations == it and np.array_equal(x, xf)
