@@ -2,6 +2,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -190,11 +191,31 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   }
   plan.n_tiles = (int)tile_fill.size();
 
-  // lane order inside a tile: by (island, list index) so that one island's
-  // constraints sit in as few wavefronts as possible.
+  // lane order inside a tile.  In the pipelined sweep constraint i runs at time
+  // ~ level(i) + D * sweep, level = depth in the list-order dependency DAG and
+  // D = the largest per-body constraint count of its island (the ticket period).
+  // Constraints with equal (level mod D) are therefore ready TOGETHER; putting
+  // them in the same wavefront turns 1/D lane utilisation into nearly full
+  // wavefronts that take turns (EGS_LANE_ORDER=0 restores island-major order).
+  std::vector<int32_t> level(m, 0), phase(m, 0);
+  {
+    std::vector<int32_t> last(n_bodies, 0), isl_period(plan.n_islands, 1);
+    for (int i = 0; i < m; ++i) {
+      int lv = 0;
+      if (body0[i] >= 0) lv = std::max(lv, last[body0[i]]);
+      if (body1[i] >= 0) lv = std::max(lv, last[body1[i]]);
+      level[i] = lv;
+      if (body0[i] >= 0) { last[body0[i]] = lv + 1; isl_period[cons_island[i]] = std::max(isl_period[cons_island[i]], cnt[body0[i]]); }
+      if (body1[i] >= 0) { last[body1[i]] = lv + 1; isl_period[cons_island[i]] = std::max(isl_period[cons_island[i]], cnt[body1[i]]); }
+    }
+    const char *env = std::getenv("EGS_LANE_ORDER");
+    const bool by_phase = !(env && std::atoi(env) == 0);
+    for (int i = 0; i < m; ++i) phase[i] = by_phase ? level[i] % isl_period[cons_island[i]] : 0;
+  }
   std::vector<int32_t> order(m);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (phase[a] != phase[b]) return phase[a] < phase[b];
     return cons_island[a] < cons_island[b];
   });
 
