@@ -100,6 +100,60 @@ def cpu_baseline(workload, budget_s):
                       "port, gcc -O2, 1 thread, %.1f s" % (done, nx, ny, nz, s.m, sweeps, prec, el)}
 
 
+def run_workload(ctx, workload, batch, method, steps, warmup, rank, torch, tdist, world):
+    """Build `batch` piles, upload, warm up, time exactly `steps` steps.  Returns a dict."""
+    nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
+    precision = capi.F32 if prec == "f32" else capi.F64
+    # `batch` independent piles per GPU; seeds differ per rank and pile (C4 style
+    # jitter of whole columns) so no two piles are identical.
+    piles = [scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=rank * batch + b + 1,
+                              origin=(0.0, 100.0 * b)) for b in range(batch)]
+    sc = scenes.concat(piles) if batch > 1 else piles[0]
+    n, m = sc["p"].shape[0], sc["kind"].shape[0]
+    Minv, f_ext = host_mass_and_force(sc)
+    t_plan = time.perf_counter()
+    pr = capi.Problem(ctx, n, sc["body0"], sc["body1"], precision)
+    t_plan = time.perf_counter() - t_plan
+    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
+    pr.set_constraints(sc["kind"], sc["data"])
+    prm = capi.params(method=method, max_iters=sweeps, tol=0.0, cfm=0.01)
+    for _ in range(warmup):
+        pr.step(dt, 0.2, prm)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    ctx.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pr.step(dt, 0.2, prm)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tdist.barrier()
+    ksum_ms, klaunches = ctx.kernel_time(reset=True)
+    st = pr.stats()
+    pr.close()
+    kernel_ms = ksum_ms / max(klaunches, 1)
+    alg_bytes = float(m) * sweeps * BYTES_PER_CONTACT_SWEEP[prec]   # per launch (one rank's batch)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = measured_traffic_per_contact("tile_solve_kernel")
+    roof = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": (traffic[0] * m) if traffic else None,
+        "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                           "measured on the 16-pile tile_solve_kernel run)" % (traffic[1], traffic[0])) if traffic else None,
+        "kernel": "quad_solve_kernel (+cons_prepare)" if st.reserved == 1 else "tile_solve_kernel",
+        "kernel_ms": kernel_ms, "launches": klaunches, "algorithmic_bytes_per_launch": alg_bytes,
+        "note": "algorithmic bytes = contacts x sweeps x %d B (SURVEY 8d); J blocks and body accumulators stay in "
+                "VGPRs/LDS across sweeps, so the achieved figure can exceed HBM peak" % BYTES_PER_CONTACT_SWEEP[prec],
+    }
+    return dict(elapsed=elapsed, n=n, m=m, sweeps=sweeps, prec=prec, dt=dt, stats=st, t_plan=t_plan, roofline=roof,
+                shape=(nx, ny, nz))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +166,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra single-pile (latency) measurement")
     args = ap.parse_args()
 
     rank, world, local = egs_dist.env_rank_world()
@@ -124,56 +179,19 @@ def main():
         torch.cuda.set_device(dev)
         egs_dist.init_process_group(args.dist_backend)
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
-
-    nx, ny, nz, sweeps, prec, dt = WORKLOADS[args.workload]
-    precision = capi.F32 if prec == "f32" else capi.F64
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
-    # `batch` independent piles per GPU; seeds differ per rank and pile (C4 style
-    # jitter of whole columns) so no two piles are identical.
-    piles = [scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=rank * args.batch + b + 1,
-                              origin=(0.0, 100.0 * b)) for b in range(args.batch)]
-    sc = scenes.concat(piles) if args.batch > 1 else piles[0]
-    n, m = sc["p"].shape[0], sc["kind"].shape[0]
-    Minv, f_ext = host_mass_and_force(sc)
-    t_plan = time.perf_counter()
-    pr = capi.Problem(ctx, n, sc["body0"], sc["body1"], precision)
-    t_plan = time.perf_counter() - t_plan
-    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
-    pr.set_constraints(sc["kind"], sc["data"])
-    prm = capi.params(method=method, max_iters=sweeps, tol=0.0, cfm=0.01)
 
-    def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            tdist.barrier()
-
-    for _ in range(args.warmup):
-        pr.step(dt, 0.2, prm)
-    sync_all()
-    ctx.kernel_time(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pr.step(dt, 0.2, prm)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tdist.barrier()
-    ksum_ms, klaunches = ctx.kernel_time(reset=True)
-    st = pr.stats()
-
+    r = run_workload(ctx, args.workload, args.batch, method, args.steps, args.warmup, rank, torch, tdist, world)
+    st, m, sweeps = r["stats"], r["m"], r["sweeps"]
     el, units, citers, resid, failed = egs_dist.reduce_stats(
-        elapsed, args.batch * args.steps, float(m) * sweeps * args.steps, st.residual, st.status != capi.OK,
+        r["elapsed"], args.batch * args.steps, float(m) * sweeps * args.steps, st.residual, st.status != capi.OK,
         device=("cuda:%d" % dev) if (world > 1 and args.dist_backend == "nccl") else None)
+    single = None
+    if world == 1 and args.batch != 1 and not args.no_single:
+        single = run_workload(ctx, args.workload, 1, method, args.steps, args.warmup, rank, torch, tdist, world)
 
     if rank == 0:
-        kernel_ms = ksum_ms / max(klaunches, 1)
-        alg_bytes = float(m) * sweeps * BYTES_PER_CONTACT_SWEEP[prec]   # per launch (one rank's batch)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        quad = st.reserved == 1   # 4-lanes-per-constraint schedule (small problems)
-        kernel = "quad_solve_kernel" if quad else "tile_solve_kernel"
-        traffic = measured_traffic_per_contact("tile_solve_kernel")
+        nx, ny, nz = r["shape"]
         out = {
             "metric": "constraint_solve_steps_per_sec",
             "value": units / el,
@@ -185,40 +203,36 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": prec,
+            "dtype": r["prec"],
             "data": "synthetic",
             "config": {
                 "workload": "%s: %dx%dx%d box pile = %d bodies, %d contacts (friction box), projected %s %d sweeps, "
                             "%s; step = assemble + solve + velocity update" % (
                                 args.workload.upper(), nx, ny, nz, nx * ny * nz, m // args.batch,
-                                "Gauss-Seidel" if method == capi.GAUSS_SEIDEL else "SOR(1.5)", sweeps, prec),
-                "piles_per_gpu": args.batch, "sweeps": sweeps, "cfm": 0.01, "dt": dt, "erp": 0.2,
+                                "Gauss-Seidel" if method == capi.GAUSS_SEIDEL else "SOR(1.5)", sweeps, r["prec"]),
+                "piles_per_gpu": args.batch, "sweeps": sweeps, "cfm": 0.01, "dt": r["dt"], "erp": 0.2,
                 "islands_per_gpu": st.n_islands, "tiles_per_gpu": st.n_tiles,
                 "schedule": "host plan (islands->tiles, %.1f ms) built once per contact topology, outside the "
-                            "timed region" % (t_plan * 1e3),
+                            "timed region" % (r["t_plan"] * 1e3),
                 "parallelism": "piles sharded x%d, no data-path collective" % world,
             },
             "contact_iters_per_sec": citers / el,
             "max_residual": resid,
             "failed": failed,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic[0] * m) if traffic else None,
-                "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                   "WRITE_SIZE, measured on the 16-pile run)" % (traffic[1], traffic[0])) if traffic else None,
-                "kernel": kernel, "kernel_ms": kernel_ms, "launches": klaunches,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "algorithmic bytes = contacts x sweeps x %d B (SURVEY 8d); J blocks and body accumulators "
-                        "stay in VGPRs/LDS across sweeps, so the achieved figure can exceed HBM peak"
-                        % BYTES_PER_CONTACT_SWEEP[prec],
-            },
+            "roofline": r["roofline"],
         }
+        if single is not None:
+            out["single_pile"] = {
+                "value": args.steps / single["elapsed"], "unit": "pile-steps/s",
+                "ms_per_step": single["elapsed"] / args.steps * 1e3,
+                "contact_iters_per_sec": float(single["m"]) * single["sweeps"] * args.steps / single["elapsed"],
+                "roofline": single["roofline"],
+                "note": "the same workload with ONE pile on the GPU (latency-bound: the dependency chain of a pile)",
+            }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
-    pr.close()
     ctx.close()
     if world > 1:
         tdist.destroy_process_group()

@@ -4,7 +4,7 @@ Prints GPU wall time (upload + Schur + Murty + download), pivots, and the CPU or
 time where it finishes in reasonable time."""
 import os, sys, time
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 from eggshell_amd import capi
 from oracle import oracle as orc

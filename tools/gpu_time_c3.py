@@ -4,16 +4,14 @@ import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
 from eggshell_amd import capi, scenes
-from oracle import oracle as orc
-from helpers import system_from_scene, ode_rhs_from_scene
+import bench
 
 ctx = capi.Context(0)
 def run(nx, ny, nz, K, batch, method=1, prec=capi.F64, steps=20):
     piles = [scenes.box_stack(nx, ny, nz, origin=(0.0, 100.0 * b)) for b in range(batch)]
     sc = scenes.concat(piles) if batch > 1 else piles[0]
     n = sc['p'].shape[0]
-    Minv = orc.minv_blocks(sc['R'], sc['mass'], sc['I_body'])
-    f_ext = orc.external_force(sc['R'], sc['w'], sc['mass'], sc['I_body'])
+    Minv, f_ext = bench.host_mass_and_force(sc)
     t = time.time()
     pr = capi.Problem(ctx, n, sc['body0'], sc['body1'], prec)
     t_plan = time.time() - t

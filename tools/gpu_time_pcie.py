@@ -6,11 +6,16 @@ import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
 from eggshell_amd import capi, scenes
-from helpers import system_from_scene, ode_rhs_from_scene
+import bench
 ctx = capi.Context(0)
 sc = scenes.box_stack(16, 16, 16)
-s, err = system_from_scene(sc)
-rhs, _ = ode_rhs_from_scene(sc, s, err, 5e-3)
+Minv, f_ext = bench.host_mass_and_force(sc)
+_pr = capi.Problem(ctx, sc['p'].shape[0], sc['body0'], sc['body1'])
+_pr.set_state(sc['p'], sc['R'], sc['v'], sc['w'], Minv, f_ext); _pr.set_constraints(sc['kind'], sc['data'])
+_pr.assemble(5e-3, 0.2)                 # the flat system (J blocks, rhs, bounds) from the device assembly
+class S: pass
+s = S(); s.Minv = Minv; s.body0 = sc['body0']; s.body1 = sc['body1']; s.n = sc['p'].shape[0]
+s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, _ = _pr.blocks(); _pr.close()
 prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=100, tol=0.0, cfm=0.01)
 for _ in range(3): ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, prm)
 t = time.perf_counter(); N = 20
