@@ -5,6 +5,7 @@ if the library is missing or no gfx950 device is usable the calls raise.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -26,7 +27,9 @@ EXPORTS = [
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
     "egs_problem_advance", "egs_problem_get_state",
     "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
-    "egs_update_contacts",
+    "egs_update_contacts", "egs_world_create", "egs_world_destroy", "egs_world_set_bodies",
+    "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
+    "egs_world_get_lambda", "egs_world_info",
 ]
 
 
@@ -86,6 +89,7 @@ def params(method=GAUSS_SEIDEL, max_iters=500, tol=1e-9, cfm=0.0, omega=1.5, che
 class Context:
     def __init__(self, device=0):
         self.h = C.c_void_p()
+        self._children = weakref.WeakSet()   # problems / worlds must be destroyed before their context
         st = load().egs_context_create(C.c_int(device), C.byref(self.h))
         if st != OK:
             self.h = C.c_void_p()
@@ -97,6 +101,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for child in list(self._children):
+                child.close()
             load().egs_context_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -169,6 +175,7 @@ class Problem:
         self.h = C.c_void_p()
         ctx.check(load().egs_problem_create(ctx.h, C.c_int32(self.n), C.c_int32(self.m), _p(self.body0),
                                             _p(self.body1), C.c_int32(precision), C.byref(self.h)))
+        ctx._children.add(self)
 
     def close(self):
         if self.h:
@@ -256,3 +263,62 @@ def debug_plan(n_bodies, body0, body1, tile_size=256):
         raise EgsError(st, "egs_debug_plan failed")
     return dict(n_islands=ni.value, n_tiles=nt.value, n_global=ng.value, cons_tile=out[0],
                 pos0=out[1], cnt0=out[2], pos1=out[3], cnt1=out[4])
+
+
+class World:
+    """Ensemble::Step resident on the device (collide -> solve -> integrate)."""
+
+    def __init__(self, ctx, n_bodies, precision=F64):
+        self.ctx, self.n = ctx, int(n_bodies)
+        self.h = C.c_void_p()
+        ctx.check(load().egs_world_create(ctx.h, C.c_int32(self.n), C.c_int32(precision), C.byref(self.h)))
+        ctx._children.add(self)
+
+    def close(self):
+        if self.h:
+            load().egs_world_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_bodies(self, pos, R, v, w, Minv, f_ext, side=None):
+        side = _f64(np.tile([0.3, 0.3, 0.3], (self.n, 1)) if side is None else side)
+        a = [_f64(pos), _f64(R), _f64(v), _f64(w), _f64(Minv), _f64(f_ext), side]
+        self.ctx.check(load().egs_world_set_bodies(self.h, *[_p(x) for x in a]))
+
+    def set_joints(self, body0, body1, data):
+        body0, body1, data = _i32(body0), _i32(body1), _f64(data)
+        self.ctx.check(load().egs_world_set_joints(self.h, C.c_int32(body0.shape[0]), _p(body0), _p(body1), _p(data)))
+
+    def step(self, dt, erp, prm, detect_contacts=True, want_stats=False):
+        st = SolveStats()
+        self.ctx.check(load().egs_world_step(self.h, C.c_double(dt), C.c_double(erp), C.byref(prm),
+                                             C.c_int32(1 if detect_contacts else 0),
+                                             C.byref(st) if want_stats else None))
+        return st
+
+    def bodies(self):
+        pos = np.zeros((self.n, 3)); R = np.zeros((self.n, 9)); v = np.zeros((self.n, 3)); w = np.zeros((self.n, 3))
+        self.ctx.check(load().egs_world_get_bodies(self.h, _p(pos), _p(R), _p(v), _p(w)))
+        return pos, R, v, w
+
+    def info(self):
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.ctx.check(load().egs_world_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_constraints=a.value, n_contacts=b.value, replans=c.value)
+
+    def contacts(self):
+        m = self.info()["n_contacts"]
+        b0 = np.zeros(m, np.int32); b1 = np.zeros(m, np.int32); data = np.zeros((m, 7)); mo = C.c_int32(0)
+        self.ctx.check(load().egs_world_get_contacts(self.h, C.c_int32(m), C.byref(mo), _p(b0), _p(b1), _p(data)))
+        return b0, b1, data
+
+    def lambda_(self):
+        rows = 3 * self.info()["n_constraints"]
+        x = np.zeros(rows); ro = C.c_int32(0)
+        self.ctx.check(load().egs_world_get_lambda(self.h, C.c_int32(rows), C.byref(ro), _p(x)))
+        return x

@@ -816,3 +816,193 @@ egs_status egs_debug_plan(int32_t n, int32_t m, const int32_t *body0, const int3
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// egs_world: Ensemble::Step (ensembles.cc:390-427) resident on the device.
+// Body state lives in the current egs_problem's buffers; each step runs
+// UpdateContacts (Collider) -> [re-plan only if the constraint topology
+// changed] -> assemble -> solve -> velocity -> StepPositions_ODE, and only the
+// contact topology (8 bytes per contact) crosses PCIe, to feed the host plan.
+struct egs_world {
+  egs_context *ctx = nullptr;
+  int n = 0, precision = EGS_F64;
+  egs_problem *prob = nullptr;
+  DevBuf<double> dside;
+  Collider col;
+  std::vector<int32_t> jb0, jb1;       // permanent constraints (joints), listed first (ensembles.cc:234-239)
+  std::vector<double> jdata;
+  std::vector<int32_t> topo_b0, topo_b1;
+  int m_contacts = 0;
+  int replans = 0;
+  bool have_bodies = false;
+};
+
+namespace {
+
+void world_make_problem(egs_world *w, const std::vector<int32_t> &b0, const std::vector<int32_t> &b1) {
+  egs_problem *np = nullptr;
+  const int m = (int)b0.size();
+  egs_status st = egs_problem_create(w->ctx, w->n, m, b0.data(), b1.data(), w->precision, &np);
+  if (st != EGS_OK) throw HipError(std::string("world: egs_problem_create: ") + egs_last_error(w->ctx));
+  hipStream_t s = w->ctx->stream;
+  if (w->prob) {  // carry the body state over, device to device
+    const size_t n = (size_t)w->n;
+    HIPCHK(hipMemcpyAsync(np->pos.p, w->prob->pos.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(np->R.p, w->prob->R.p, n * 9 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(np->v.p, w->prob->v.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(np->w.p, w->prob->w.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(np->Minv_d.p, w->prob->Minv_d.p, n * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(np->f_ext.p, w->prob->f_ext.p, n * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    egs_problem_destroy(w->prob);
+    np->have_state = true;
+  }
+  // constraint kinds: joints first, then contacts; joint descriptors are static
+  std::vector<int32_t> kind((size_t)(m > 0 ? m : 1), EGS_CONTACT_BOX);
+  const int mj = (int)w->jb0.size();
+  for (int i = 0; i < mj; ++i) kind[i] = EGS_JOINT_BALL;
+  if (m > 0) {
+    upload(np->kind, kind.data(), (size_t)m, s);
+    if (mj > 0) upload(np->data, w->jdata.data(), (size_t)mj * 7, s);
+  }
+  np->have_constraints = true;
+  np->minv_r_valid = false;
+  w->prob = np;
+  w->topo_b0 = b0; w->topo_b1 = b1;
+  ++w->replans;
+}
+
+}  // namespace
+
+extern "C" {
+
+egs_status egs_world_create(egs_context *ctx, int32_t n_bodies, int32_t precision, egs_world **out) {
+  if (!ctx || !out || n_bodies < 0) return EGS_ERR_INVALID;
+  *out = nullptr;
+  if (precision != EGS_F64 && precision != EGS_F32) return fail(ctx, EGS_ERR_INVALID, "unknown precision");
+  egs_world *w = new (std::nothrow) egs_world;
+  if (!w) return fail(ctx, EGS_ERR_HIP, "host allocation failed");
+  w->ctx = ctx; w->n = n_bodies; w->precision = precision;
+  egs_status st = guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    w->dside.alloc((size_t)(n_bodies > 0 ? n_bodies : 1) * 3);
+    return EGS_OK;
+  });
+  if (st != EGS_OK) { delete w; return st; }
+  *out = w;
+  return EGS_OK;
+}
+
+void egs_world_destroy(egs_world *w) {
+  if (!w) return;
+  if (w->prob) egs_problem_destroy(w->prob);
+  delete w;
+}
+
+egs_status egs_world_set_bodies(egs_world *w, const double *pos, const double *R, const double *v, const double *wv,
+                                const double *Minv, const double *f_ext, const double *side_lengths) {
+  if (!w) return EGS_ERR_INVALID;
+  if (w->n > 0 && (!pos || !R || !v || !wv || !Minv || !f_ext || !side_lengths))
+    return fail(w->ctx, EGS_ERR_INVALID, "NULL array");
+  return guarded(w->ctx, [&]() -> egs_status {
+    if (!w->prob) world_make_problem(w, w->jb0, w->jb1);
+    egs_status st = egs_problem_set_state(w->prob, pos, R, v, wv, Minv, f_ext);
+    if (st != EGS_OK) return st;
+    upload(w->dside, side_lengths, (size_t)w->n * 3, w->ctx->stream);
+    w->have_bodies = true;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_world_set_joints(egs_world *w, int32_t m_joints, const int32_t *body0, const int32_t *body1,
+                                const double *data) {
+  if (!w || m_joints < 0 || (m_joints > 0 && (!body0 || !body1 || !data))) return EGS_ERR_INVALID;
+  w->jb0.assign(body0, body0 + m_joints);
+  w->jb1.assign(body1, body1 + m_joints);
+  w->jdata.assign(data, data + (size_t)m_joints * 7);
+  return guarded(w->ctx, [&]() -> egs_status {
+    std::vector<int32_t> b0 = w->jb0, b1 = w->jb1;   // contacts are re-detected by the next step
+    world_make_problem(w, b0, b1);
+    w->m_contacts = 0;
+    return EGS_OK;
+  });
+}
+
+egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_params *params,
+                          int32_t detect_contacts, egs_solve_stats *stats) {
+  if (!w) return EGS_ERR_INVALID;
+  if (!w->have_bodies) return fail(w->ctx, EGS_ERR_INVALID, "egs_world_set_bodies first");
+  if (!(dt > 0)) return fail(w->ctx, EGS_ERR_INVALID, "dt must be > 0");
+  return guarded(w->ctx, [&]() -> egs_status {
+    hipStream_t s = w->ctx->stream;
+    const int mj = (int)w->jb0.size();
+    if (detect_contacts) {  // UpdateContacts + pruning on the device (ensembles.cc:393-394)
+      const int mc = w->col.run(s, w->n, w->prob->pos.p, w->prob->R.p, w->dside.p);
+      std::vector<int32_t> b0(w->jb0), b1(w->jb1);
+      b0.resize((size_t)mj + mc); b1.resize((size_t)mj + mc);
+      if (mc > 0) {
+        HIPCHK(hipMemcpyAsync(b0.data() + mj, w->col.body0(), (size_t)mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(b1.data() + mj, w->col.body1(), (size_t)mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      if (b0 != w->topo_b0 || b1 != w->topo_b1) world_make_problem(w, b0, b1);  // host plan only on topology change
+      if (mc > 0)
+        HIPCHK(hipMemcpyAsync(w->prob->data.p + (size_t)mj * 7, w->col.data(), (size_t)mc * 7 * sizeof(double),
+                              hipMemcpyDeviceToDevice, s));
+      w->m_contacts = mc;
+    }
+    egs_problem *p = w->prob;
+    if (p->m > 0) {
+      do_assemble(p, dt, erp);
+      egs_status st = do_solve(p, params, stats);
+      if (st != EGS_OK) return st;
+    } else {  // no constraints: v_dot = M^-1 f (ensembles.cc:504-505)
+      if (egs_status st = validate_params(w->ctx, params)) return st;
+      HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * p->real_size(), s));
+      if (stats) { std::memset(stats, 0, sizeof *stats); fill_stats(p, stats); }
+    }
+    do_velocity(p, dt);
+    launch_advance(p->n, p->pos.p, p->R.p, p->v.p, p->w.p, p->v6.p, dt, s);
+    HIPCHK(hipGetLastError());
+    return EGS_OK;
+  });
+}
+
+egs_status egs_world_get_bodies(egs_world *w, double *pos, double *R, double *v, double *wv) {
+  if (!w || !w->prob) return EGS_ERR_INVALID;
+  return egs_problem_get_state(w->prob, pos, R, v, wv);
+}
+
+egs_status egs_world_get_contacts(egs_world *w, int32_t max_contacts, int32_t *m_out, int32_t *body0, int32_t *body1,
+                                  double *data) {
+  if (!w || !m_out) return EGS_ERR_INVALID;
+  *m_out = w->m_contacts;
+  if (w->m_contacts > max_contacts) return fail(w->ctx, EGS_ERR_INVALID, "max_contacts too small");
+  return guarded(w->ctx, [&]() -> egs_status {
+    const size_t mc = (size_t)w->m_contacts;
+    hipStream_t s = w->ctx->stream;
+    if (mc && body0) HIPCHK(hipMemcpyAsync(body0, w->col.body0(), mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (mc && body1) HIPCHK(hipMemcpyAsync(body1, w->col.body1(), mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (mc && data) HIPCHK(hipMemcpyAsync(data, w->col.data(), mc * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return EGS_OK;
+  });
+}
+
+egs_status egs_world_get_lambda(egs_world *w, int32_t max_rows, int32_t *rows_out, double *lambda) {
+  if (!w || !w->prob || !rows_out) return EGS_ERR_INVALID;
+  *rows_out = 3 * w->prob->m;
+  if (3 * w->prob->m > max_rows) return fail(w->ctx, EGS_ERR_INVALID, "max_rows too small");
+  if (w->prob->m == 0) return EGS_OK;
+  return egs_problem_get_lambda(w->prob, lambda);
+}
+
+egs_status egs_world_info(egs_world *w, int32_t *n_constraints, int32_t *n_contacts, int32_t *replans) {
+  if (!w) return EGS_ERR_INVALID;
+  if (n_constraints) *n_constraints = w->prob ? w->prob->m : 0;
+  if (n_contacts) *n_contacts = w->m_contacts;
+  if (replans) *replans = w->replans;
+  return EGS_OK;
+}
+
+}  // extern "C"

@@ -14,4 +14,25 @@ namespace egs {
 int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
                     int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs);
 
+// Device-resident form: body state already on the device, the contact list stays
+// there (body0()/body1()/data() are device pointers valid until the next run()).
+class Collider {
+ public:
+  Collider();
+  ~Collider();
+  Collider(const Collider &) = delete;
+  Collider &operator=(const Collider &) = delete;
+  int run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside);  // returns m
+  const int32_t *body0() const;
+  const int32_t *body1() const;
+  const double *data() const;
+  int n_ground() const { return n_ground_; }
+  int n_pairs() const { return n_pairs_; }
+
+ private:
+  struct Impl;
+  Impl *impl_;
+  int n_ground_ = 0, n_pairs_ = 0;
+};
+
 }  // namespace egs

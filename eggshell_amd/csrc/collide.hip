@@ -440,6 +440,71 @@ int exclusive_scan(hipStream_t s, int n, const int *in, int *out, int *scratch_b
 
 }  // namespace
 
+// ---- device-resident collider ---------------------------------------------
+struct Collider::Impl {
+  // growable device buffers
+  template <typename T>
+  struct G {
+    T *p = nullptr;
+    size_t cap = 0;
+    void need(size_t n) {
+      if (n <= cap) return;
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = n + n / 4 + 64;
+      HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T)));
+    }
+    ~G() { if (p) (void)hipFree(p); }
+  };
+  G<int> gcount, goff, ccount, coff, cand, flags, blocks, pi, pj, pcount, poff, blocks2, b0, b1;
+  G<double> data;
+};
+
+Collider::Collider() : impl_(new Impl) {}
+Collider::~Collider() { delete impl_; }
+const int32_t *Collider::body0() const { return impl_->b0.p; }
+const int32_t *Collider::body1() const { return impl_->b1.p; }
+const double *Collider::data() const { return impl_->data.p; }
+
+int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside) {
+  Impl &I = *impl_;
+  n_ground_ = 0; n_pairs_ = 0;
+  if (n <= 0) return 0;
+  const size_t nn = (size_t)n;
+  I.gcount.need(nn); I.goff.need(nn); I.ccount.need(nn); I.coff.need(nn); I.cand.need(nn * KMAX); I.flags.need(2);
+  I.blocks.need((nn + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
+  HIPCHK(hipMemsetAsync(I.flags.p, 0, 2 * sizeof(int), s));
+  const int gb = (n + 255) / 256;
+  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos, dR, dside, (const int *)nullptr, I.gcount.p,
+                     (int *)nullptr, (int *)nullptr, (double *)nullptr);
+  const int G = exclusive_scan(s, n, I.gcount.p, I.goff.p, I.blocks.p, I.flags.p + 1);
+  hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.cand.p, I.ccount.p, I.flags.p);
+  const int C = exclusive_scan(s, n, I.ccount.p, I.coff.p, I.blocks.p, I.flags.p + 1);
+  int overflow = 0;
+  HIPCHK(hipMemcpyAsync(&overflow, I.flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (overflow) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
+  int P = 0;
+  if (C > 0) {
+    I.pi.need(C); I.pj.need(C); I.pcount.need(C); I.poff.need(C); I.blocks2.need(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
+    hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, I.cand.p, I.ccount.p, I.coff.p, I.pi.p, I.pj.p);
+    hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
+                       (const int *)nullptr, 0, I.pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr);
+    P = exclusive_scan(s, C, I.pcount.p, I.poff.p, I.blocks2.p, I.flags.p + 1);
+  }
+  const int m = G + P;
+  n_ground_ = G; n_pairs_ = C;
+  if (m == 0) return 0;
+  I.b0.need(m); I.b1.need(m); I.data.need((size_t)m * 7);
+  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos, dR, dside, I.goff.p, (int *)nullptr, I.b0.p,
+                     I.b1.p, I.data.p);
+  if (C > 0)
+    hipLaunchKernelGGL((narrow_kernel<true>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
+                       I.poff.p, G, (int *)nullptr, I.b0.p, I.b1.p, I.data.p);
+  HIPCHK(hipGetLastError());
+  return m;
+}
+
 int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
                     int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs) {
   if (n_ground) *n_ground = 0;
@@ -447,47 +512,19 @@ int update_contacts(hipStream_t s, int n, const double *pos, const double *R, co
   if (n <= 0) return 0;
   const size_t nn = (size_t)n;
   Buf<double> dpos(nn * 3), dR(nn * 9), dside(nn * 3);
-  Buf<int> gcount(nn), goff(nn), ccount(nn), coff(nn), cand(nn * KMAX), flags(2);
-  Buf<int> blocks((nn * 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1024);
   HIPCHK(hipMemcpyAsync(dpos.p, pos, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dR.p, R, nn * 9 * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dside.p, side, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), s));
-  const int gb = (n + 255) / 256;
-  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos.p, dR.p, dside.p, (const int *)nullptr, gcount.p,
-                     (int *)nullptr, (int *)nullptr, (double *)nullptr);
-  const int G = exclusive_scan(s, n, gcount.p, goff.p, blocks.p, flags.p + 1);
-  hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos.p, dside.p, cand.p, ccount.p, flags.p);
-  const int C = exclusive_scan(s, n, ccount.p, coff.p, blocks.p, flags.p + 1);
-  int overflow = 0;
-  HIPCHK(hipMemcpyAsync(&overflow, flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (overflow) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
-  Buf<int> pi((size_t)C), pj((size_t)C), pcount((size_t)C), poff((size_t)C), blocks2(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
-  int P = 0;
-  if (C > 0) {
-    hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, cand.p, ccount.p, coff.p, pi.p, pj.p);
-    hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, pi.p, pj.p, dpos.p, dR.p, dside.p,
-                       (const int *)nullptr, 0, pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr);
-    P = exclusive_scan(s, C, pcount.p, poff.p, blocks2.p, flags.p + 1);
-  }
-  const int m = G + P;
-  if (n_ground) *n_ground = G;
-  if (n_pairs) *n_pairs = C;
+  Collider col;
+  const int m = col.run(s, n, dpos.p, dR.p, dside.p);
+  if (n_ground) *n_ground = col.n_ground();
+  if (n_pairs) *n_pairs = col.n_pairs();
   if (m > max_contacts) throw std::invalid_argument("update_contacts: max_contacts too small (" + std::to_string(m) + " needed)");
   if (m == 0) return 0;
-  Buf<int> db0((size_t)m), db1((size_t)m);
-  Buf<double> ddata((size_t)m * 7);
-  hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos.p, dR.p, dside.p, goff.p, (int *)nullptr, db0.p,
-                     db1.p, ddata.p);
-  if (C > 0)
-    hipLaunchKernelGGL((narrow_kernel<true>), dim3((C + 63) / 64), dim3(64), 0, s, C, pi.p, pj.p, dpos.p, dR.p, dside.p,
-                       poff.p, G, (int *)nullptr, db0.p, db1.p, ddata.p);
-  HIPCHK(hipMemcpyAsync(body0, db0.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(body1, db1.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(data, ddata.p, (size_t)m * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(body0, col.body0(), (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(body1, col.body1(), (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(data, col.data(), (size_t)m * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
   return m;
 }
 

@@ -223,7 +223,10 @@ Ensemble::Ensemble() {
   egs_default_params(&solver_params);
   solver_params.method = EGS_SOR;
 }
-Ensemble::~Ensemble() { if (problem_) egs_problem_destroy(problem_); }
+Ensemble::~Ensemble() {
+  if (problem_) egs_problem_destroy(problem_);
+  if (world_) egs_world_destroy(world_);
+}
 
 void Ensemble::Init() {  // ensembles.cc:24-29
   ConstructMassInertiaMatrixInverse();
@@ -416,9 +419,83 @@ void Ensemble::UpdateContacts() {  // ensembles.cc:445-480 (+ :308-328)
   }
 }
 
+// The whole Step through egs_world (include/eggshell_amd.h): possible when every
+// permanent constraint can describe itself (ball joints) -- contacts always can.
+// Body objects are the interface, so their state is pushed before and pulled
+// after the step; inside the step nothing but the contact topology leaves the GPU.
+bool Ensemble::StepOnDevice(double dt) {
+  if (!use_device_step) return false;
+  const int mj = (int)joints_.size();
+  std::vector<int32_t> jb0(mj), jb1(mj), kind(1);
+  std::vector<double> jdata((size_t)mj * 7);
+  for (int i = 0; i < mj; ++i) {
+    jb0[i] = joints_[i]->i0_; jb1[i] = joints_[i]->i1_;
+    if (!joints_[i]->Describe(&kind[0], &jdata[(size_t)i * 7])) return false;
+  }
+  if (!detect_contacts && !contacts_.empty()) return false;   // caller-supplied contacts: use the explicit path
+  egs_context *ctx = egs::DefaultContext();
+  if (!world_) {
+    egs::check(egs_world_create(ctx, n_, EGS_F64, &world_));
+    world_joints_ = -1;
+  }
+  std::vector<double> pos((size_t)n_ * 3), R((size_t)n_ * 9), vl((size_t)n_ * 3), w((size_t)n_ * 3), Minv((size_t)n_ * 36),
+      side((size_t)n_ * 3);
+  for (int i = 0; i < n_; ++i) {
+    const Vector3d sl = components_[i]->GetSideLengths();
+    for (int k = 0; k < 3; ++k) {
+      pos[3 * i + k] = components_[i]->p()[k]; vl[3 * i + k] = components_[i]->v()[k];
+      w[3 * i + k] = components_[i]->w_g()[k]; side[3 * i + k] = sl[k];
+    }
+    for (int k = 0; k < 9; ++k) R[9 * i + k] = components_[i]->R().d[k];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) Minv[(size_t)i * 36 + 6 * r + c] = M_inverse_(6 * i + r, 6 * i + c);
+  }
+  egs::check(egs_world_set_bodies(world_, pos.data(), R.data(), vl.data(), w.data(), Minv.data(),
+                                  external_force_torque_.data(), side.data()));
+  if (world_joints_ != mj) {   // joints are permanent (ensembles.cc:331-334)
+    egs::check(egs_world_set_joints(world_, mj, jb0.data(), jb1.data(), jdata.data()));
+    world_joints_ = mj;
+  }
+  egs_solve_params prm = solver_params;
+  prm.cfm = cfm_coeff;
+  egs_solve_stats st;
+  egs::check(egs_world_step(world_, dt, /*erp=*/0.2, &prm, detect_contacts ? 1 : 0, &st));
+  egs::check(egs_world_get_bodies(world_, pos.data(), R.data(), vl.data(), w.data()));
+  for (int i = 0; i < n_; ++i) {
+    components_[i]->SetP(Vector3d(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+    components_[i]->SetV(Vector3d(vl[3 * i], vl[3 * i + 1], vl[3 * i + 2]));
+    components_[i]->SetW_GlobalFrame(Vector3d(w[3 * i], w[3 * i + 1], w[3 * i + 2]));
+    Matrix3d Rm;
+    for (int k = 0; k < 9; ++k) Rm.d[k] = R[9 * i + k];
+    components_[i]->SetR(Rm);
+  }
+  int32_t mcons = 0, mc = 0, replans = 0;
+  egs::check(egs_world_info(world_, &mcons, &mc, &replans));
+  contacts_.clear();
+  if (mc > 0) {   // the contact list the step used (for constraints(), Draw(), ...)
+    std::vector<int32_t> b0(mc), b1(mc);
+    std::vector<double> data((size_t)mc * 7);
+    int32_t got = 0;
+    egs::check(egs_world_get_contacts(world_, mc, &got, b0.data(), b1.data(), data.data()));
+    for (int k = 0; k < mc; ++k) {
+      const double *d = &data[(size_t)k * 7];
+      ContactGeometry cg(Vector3d(d[0], d[1], d[2]), Vector3d(d[3], d[4], d[5]), d[6]);
+      if (b0[k] < 0) contacts_.push_back(std::make_shared<Contact>(components_[b1[k]], b1[k], cg));
+      else contacts_.push_back(std::make_shared<Contact>(components_[b0[k]], b0[k], components_[b1[k]], b1[k], cg));
+    }
+  }
+  last_lambda.resize(3 * mcons);
+  if (mcons > 0) {
+    int32_t rows = 0;
+    egs::check(egs_world_get_lambda(world_, 3 * mcons, &rows, last_lambda.data()));
+  }
+  return true;
+}
+
 void Ensemble::Step(double dt, Integrator g) {  // ensembles.cc:390-427
   if (g != Integrator::OPEN_DYNAMICS_ENGINE)
     throw egs::Error(EGS_ERR_UNSUPPORTED, "only Integrator::OPEN_DYNAMICS_ENGINE is on the accelerated path");
+  if (StepOnDevice(dt)) return;   // collide -> solve -> integrate in one resident pipeline
   const VectorXd v = GetVelocities();
   if (detect_contacts) UpdateContacts();
   VectorXd v_new = StepVelocities_ODE(dt, v);

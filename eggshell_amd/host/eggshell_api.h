@@ -175,6 +175,7 @@ class Ensemble {  // ensembles.h:25-186
   // update contacts_ (ensembles.cc:445-480), then drop contacts closer than
   // 1e-6 to an earlier contact of the same pair (ensembles.cc:308-328): on the GPU.
   void UpdateContacts();
+  bool use_device_step = true;   // false: the explicit UpdateContacts / StepVelocities_ODE / StepPositions_ODE calls
   bool detect_contacts = true;   // Step() calls UpdateContacts() as the reference does (ensembles.cc:393)
   const VectorXd GetVelocities() const;                                  // ensembles.cc:429-436
   VectorXd ComputePositionConstraintError() const;                       // ensembles.cc:156-171
@@ -199,6 +200,9 @@ class Ensemble {  // ensembles.h:25-186
   void UpdateComponentsVelocities(const VectorXd &v);                    // ensembles.cc:438-443
   VectorXd StepVelocities_ODE(double dt, const VectorXd &v, double error_reduction_param = 0.2);  // :563-575
   void StepPositions_ODE(double dt, const VectorXd &v, const VectorXd &v_new);                    // :577-591
+  bool StepOnDevice(double dt);
+  egs_world *world_ = nullptr;
+  int world_joints_ = -1;
   egs_problem *problem_ = nullptr;
   std::vector<int32_t> plan_b0_, plan_b1_;   // topology the cached device problem was planned for
 };

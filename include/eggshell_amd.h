@@ -199,6 +199,33 @@ egs_status egs_update_contacts(egs_context *ctx, int32_t n_bodies,
                                int32_t *m_out, int32_t *body0, int32_t *body1,
                                double *data);
 
+/* ---- the whole Ensemble::Step on the device ------------------------------
+ * Ensemble::Step(dt, OPEN_DYNAMICS_ENGINE) (ensembles.cc:390-427) with the
+ * sparse switch on: UpdateContacts + contact pruning, StepVelocities_ODE
+ * (assembly, rhs, projected solve, velocity update) and StepPositions_ODE all
+ * run on the GPU and the body state stays there between steps.  Only the
+ * contact TOPOLOGY (body index pairs) is read back each step; the schedule is
+ * re-planned on the host only when it changed.  Constraint list order as in
+ * the reference: joints first, then contacts (ensembles.cc:234-239).         */
+typedef struct egs_world egs_world;
+egs_status egs_world_create(egs_context *ctx, int32_t n_bodies, int32_t precision, egs_world **out);
+void egs_world_destroy(egs_world *w);
+/* pos [n][3], R [n][9], v, w [n][3], Minv [n][36], f_ext [n][6] (frozen as
+ * Ensemble::Init leaves them, quirk Q5), side_lengths [n][3] (body.h:91). */
+egs_status egs_world_set_bodies(egs_world *w, const double *pos, const double *R, const double *v,
+                                const double *w_ang, const double *Minv, const double *f_ext,
+                                const double *side_lengths);
+/* ball joints: body0/body1 [m], data [m][7] = c0, c1 (world point if body1 = -1), 0 */
+egs_status egs_world_set_joints(egs_world *w, int32_t m_joints, const int32_t *body0, const int32_t *body1,
+                                const double *data);
+egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_params *params,
+                          int32_t detect_contacts, egs_solve_stats *stats);
+egs_status egs_world_get_bodies(egs_world *w, double *pos, double *R, double *v, double *w_ang);
+egs_status egs_world_get_contacts(egs_world *w, int32_t max_contacts, int32_t *m_out, int32_t *body0,
+                                  int32_t *body1, double *data);
+egs_status egs_world_get_lambda(egs_world *w, int32_t max_rows, int32_t *rows_out, double *lambda);
+egs_status egs_world_info(egs_world *w, int32_t *n_constraints, int32_t *n_contacts, int32_t *replans);
+
 /* ---- diagnostics (host only, needs no GPU) -------------------------------
  * The schedule the solver derives from the constraint graph: islands, the
  * workgroup tile each constraint lands in (-1 = cross-workgroup path) and the
