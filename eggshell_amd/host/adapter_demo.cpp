@@ -85,6 +85,34 @@ int main(int argc, char **argv) {
       print_vec("drop_v", drop.GetVelocities());
       std::printf("drop_contacts %d\n", contacts_seen);
     }
+    {
+      // InitStabilize / PostStabilize (ensembles.cc:602-646): a Chain(4) whose
+      // links were pulled off their joints relaxes back onto the constraint manifold.
+      Chain bent(4, Vector3d(0, 0, 2));
+      bent.Init();
+      for (int i = 1; i < 4; ++i) {
+        const Vector3d p = bent.components()[i]->p();
+        bent.components()[i]->SetP(p + Vector3d(0.01 * i, -0.02 * i, 0.015 * i));
+      }
+      bent.InitStabilize();
+      VectorXd sp(12);
+      for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 3; ++k) sp(3 * i + k) = bent.components()[i]->p()[k];
+      print_vec("stab_p", sp);
+      print_vec("stab_err", bent.ComputePositionConstraintError());
+      std::printf("stab_steps %d\n", bent.last_stabilize_steps);
+      for (int i = 1; i < 4; ++i) {
+        const Vector3d p = bent.components()[i]->p();
+        bent.components()[i]->SetP(p + Vector3d(-0.02, 0.01 * i, 0.0));
+        bent.components()[i]->SetV(Vector3d(0.1, 0.0, -0.2));
+      }
+      bent.PostStabilize();
+      for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 3; ++k) sp(3 * i + k) = bent.components()[i]->p()[k];
+      print_vec("post_p", sp);
+      print_vec("post_v", bent.GetVelocities());
+      std::printf("post_steps %d\n", bent.last_stabilize_steps);
+    }
     if (argc > 1 && !std::strcmp(argv[1], "--dense")) {
       // Lcp::MixedConstraintsSolver on the reference's literal 5x5 (lcp.cc:369-376)
       const double a[25] = {2.1104, 1.4090, 1.5055, 1.3060, 1.1413, 1.4090, 1.9846, 1.7126, 1.0858, 1.9358, 1.5055, 1.7126, 2.1673,

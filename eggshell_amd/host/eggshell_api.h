@@ -167,6 +167,11 @@ class Ensemble {  // ensembles.h:25-186
   // the caller's until the collision row is built), velocities by the
   // matrix-free projected SOR on the GPU, positions by the midpoint rule.
   virtual void Step(double dt, Integrator g = Integrator::OPEN_DYNAMICS_ENGINE);
+  // When Ensemble is first initialized, check for position errors, correct them
+  // with StepPositionRelaxation (ensembles.cc:602-622); PostStabilize brings
+  // positions AND velocities back to the constraint manifold (ensembles.cc:624-646).
+  void InitStabilize();
+  void PostStabilize(int max_steps = 500);
   const MatrixXd &M_inverse() const { return M_inverse_; }
   const ConstraintsList constraints() const { return CombineConstraintsLists(); }
   const ComponentsList &components() const { return components_; }
@@ -183,6 +188,7 @@ class Ensemble {  // ensembles.h:25-186
   egs_solve_params solver_params;
   double cfm_coeff = 0.01;                                               // kCfmCoeff, ensembles.cc:14
   VectorXd last_lambda;
+  int last_stabilize_steps = 0;
 
  protected:
   Ensemble();
@@ -201,6 +207,13 @@ class Ensemble {  // ensembles.h:25-186
   VectorXd StepVelocities_ODE(double dt, const VectorXd &v, double error_reduction_param = 0.2);  // :563-575
   void StepPositions_ODE(double dt, const VectorXd &v, const VectorXd &v_new);                    // :577-591
   bool StepOnDevice(double dt);
+  // -step_scale * J^T (J J^T)^-1 err (ensembles.cc:659-666); the SPD(-semidefinite)
+  // solve runs matrix-free on the GPU: the same projected sweep with M^-1 = I and
+  // every row an equality.
+  VectorXd CalculateVelocityRelaxation(double step_scale) const;
+  void StepPositions_ExplicitEuler(double dt, const VectorXd &v);          // ensembles.cc:553-561
+  void StepPositionRelaxation(double dt, double step_scale = 0.2);         // ensembles.cc:648-651
+  void StepPostStabilization(double dt, double step_scale = 0.2);          // ensembles.cc:653-658
   egs_world *world_ = nullptr;
   int world_joints_ = -1;
   egs_problem *problem_ = nullptr;
