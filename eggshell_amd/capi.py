@@ -27,7 +27,7 @@ EXPORTS = [
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
     "egs_problem_advance", "egs_problem_get_state",
     "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
-    "egs_update_contacts", "egs_world_create", "egs_world_destroy", "egs_world_set_bodies",
+    "egs_update_contacts", "egs_update_contacts_joints", "egs_world_create", "egs_world_destroy", "egs_world_set_bodies",
     "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
     "egs_world_get_lambda", "egs_world_info",
 ]
@@ -141,9 +141,21 @@ class Context:
                                            C.byref(prm), C.c_int32(precision), _p(x), C.byref(st)))
         return x, st
 
-    def update_contacts(self, pos, R, side=None, max_contacts=None):
-        """Ensemble::UpdateContacts + contact pruning on the GPU (reference order)."""
+    def update_contacts(self, pos, R, side=None, max_contacts=None, joints=None):
+        """Ensemble::UpdateContacts + contact pruning on the GPU (reference order).
+        joints = (body0, body1, data[m][7]) adds the joint-vs-contact pruning."""
         pos, R = _f64(pos), _f64(R)
+        if joints is not None:
+            jb0, jb1, jd = _i32(joints[0]), _i32(joints[1]), _f64(joints[2])
+            n = pos.reshape(-1, 3).shape[0]
+            side = _f64(np.tile([0.3, 0.3, 0.3], (n, 1)) if side is None else side)
+            cap = int(max_contacts if max_contacts is not None else 64 * n + 64)
+            b0 = np.zeros(cap, np.int32); b1 = np.zeros(cap, np.int32); data = np.zeros((cap, 7))
+            m = C.c_int32(0)
+            self.check(load().egs_update_contacts_joints(self.h, C.c_int32(n), _p(pos), _p(R), _p(side),
+                                                         C.c_int32(jb0.shape[0]), _p(jb0), _p(jb1), _p(jd), C.c_int32(cap),
+                                                         C.byref(m), _p(b0), _p(b1), _p(data)))
+            return b0[:m.value].copy(), b1[:m.value].copy(), data[:m.value].copy()
         n = pos.reshape(-1, 3).shape[0]
         side = _f64(np.tile([0.3, 0.3, 0.3], (n, 1)) if side is None else side)
         cap = int(max_contacts if max_contacts is not None else 64 * n + 64)

@@ -768,6 +768,29 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
   });
 }
 
+egs_status egs_update_contacts_joints(egs_context *ctx, int32_t n, const double *pos, const double *R,
+                                      const double *side, int32_t m_joints, const int32_t *jb0, const int32_t *jb1,
+                                      const double *jdata, int32_t max_contacts, int32_t *m_out, int32_t *body0,
+                                      int32_t *body1, double *data) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (n < 0 || m_joints < 0 || !m_out || (n > 0 && (!pos || !R || !side)) || (m_joints > 0 && (!jb0 || !jb1 || !jdata)) ||
+      (max_contacts > 0 && (!body0 || !body1 || !data)))
+    return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  for (int q = 0; q < m_joints; ++q)
+    if (jb0[q] < -1 || jb0[q] >= n || jb1[q] < -1 || jb1[q] >= n) return fail(ctx, EGS_ERR_INVALID, "joint body index out of range");
+  *m_out = 0;
+  // only body-body joints can prune (the pair scan never visits the ground, quirk Q4)
+  std::vector<int32_t> b0, b1; std::vector<double> jd;
+  for (int q = 0; q < m_joints; ++q)
+    if (jb0[q] >= 0 && jb1[q] >= 0) { b0.push_back(jb0[q]); b1.push_back(jb1[q]); jd.insert(jd.end(), jdata + 7 * (size_t)q, jdata + 7 * (size_t)q + 7); }
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    *m_out = update_contacts(ctx->stream, n, pos, R, side, max_contacts, body0, body1, data, nullptr, nullptr,
+                             (int)b0.size(), b0.data(), b1.data(), jd.data());
+    return EGS_OK;
+  });
+}
+
 egs_status egs_update_contacts(egs_context *ctx, int32_t n, const double *pos, const double *R, const double *side,
                                int32_t max_contacts, int32_t *m_out, int32_t *body0, int32_t *body1, double *data) {
   if (!ctx) return EGS_ERR_INVALID;
@@ -831,6 +854,8 @@ struct egs_world {
   Collider col;
   std::vector<int32_t> jb0, jb1;       // permanent constraints (joints), listed first (ensembles.cc:234-239)
   std::vector<double> jdata;
+  DevBuf<int32_t> djb0, djb1;          // the same on the device, for joint-vs-contact pruning
+  DevBuf<double> djdata;
   std::vector<int32_t> topo_b0, topo_b1;
   int m_contacts = 0;
   int replans = 0;
@@ -921,6 +946,12 @@ egs_status egs_world_set_joints(egs_world *w, int32_t m_joints, const int32_t *b
   w->jb1.assign(body1, body1 + m_joints);
   w->jdata.assign(data, data + (size_t)m_joints * 7);
   return guarded(w->ctx, [&]() -> egs_status {
+    w->djb0.alloc((size_t)m_joints); w->djb1.alloc((size_t)m_joints); w->djdata.alloc((size_t)m_joints * 7);
+    if (m_joints > 0) {
+      upload(w->djb0, body0, (size_t)m_joints, w->ctx->stream);
+      upload(w->djb1, body1, (size_t)m_joints, w->ctx->stream);
+      upload(w->djdata, data, (size_t)m_joints * 7, w->ctx->stream);
+    }
     std::vector<int32_t> b0 = w->jb0, b1 = w->jb1;   // contacts are re-detected by the next step
     world_make_problem(w, b0, b1);
     w->m_contacts = 0;
@@ -937,7 +968,7 @@ egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_p
     hipStream_t s = w->ctx->stream;
     const int mj = (int)w->jb0.size();
     if (detect_contacts) {  // UpdateContacts + pruning on the device (ensembles.cc:393-394)
-      const int mc = w->col.run(s, w->n, w->prob->pos.p, w->prob->R.p, w->dside.p);
+      const int mc = w->col.run(s, w->n, w->prob->pos.p, w->prob->R.p, w->dside.p, mj, w->djb0.p, w->djb1.p, w->djdata.p);
       std::vector<int32_t> b0(w->jb0), b1(w->jb1);
       b0.resize((size_t)mj + mc); b1.resize((size_t)mj + mc);
       if (mc > 0) {

@@ -12,7 +12,8 @@ namespace egs {
 // Throws std::invalid_argument if m > max_contacts or a body has more than 64
 // overlapping partners.
 int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
-                    int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs);
+                    int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs, int mj = 0,
+                    const int32_t *jb0 = nullptr, const int32_t *jb1 = nullptr, const double *jdata = nullptr);
 
 // Device-resident form: body state already on the device, the contact list stays
 // there (body0()/body1()/data() are device pointers valid until the next run()).
@@ -22,7 +23,10 @@ class Collider {
   ~Collider();
   Collider(const Collider &) = delete;
   Collider &operator=(const Collider &) = delete;
-  int run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside);  // returns m
+  // optional joints (device arrays, body-body only matter): contacts within 1e-6 of a
+  // joint between the same two bodies are dropped (ensembles.cc:296-306)
+  int run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside, int mj = 0,
+          const int32_t *djb0 = nullptr, const int32_t *djb1 = nullptr, const double *djdata = nullptr);  // returns m
   const int32_t *body0() const;
   const int32_t *body1() const;
   const double *data() const;

@@ -368,10 +368,14 @@ __global__ void __launch_bounds__(256) flatten_kernel(int n, const int *cand, co
 // Narrow phase + contact-vs-contact pruning within the pair
 // (ensembles.cc:308-316, kMinConstraintDistance = 1e-6: a contact is deleted if
 // ANY earlier contact of the same pair lies within 1e-6 of it).
+// Joints between the same two bodies prune contacts within 1e-6 of the joint
+// position (ensembles.cc:296-306; Joint::GetConstraintPosition, joints.cc:57-75).
+struct JointList { int mj; const int *b0, *b1; const double *data; };
+
 template <bool EMIT>
 __global__ void __launch_bounds__(64) narrow_kernel(int npairs, const int *pi, const int *pj, const double *pos,
                                                     const double *R, const double *side, const int *off, int base,
-                                                    int *count, int *b0, int *b1, double *data) {
+                                                    int *count, int *b0, int *b1, double *data, JointList jl) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= npairs) return;
   const int i = pi[t], j = pj[t];
@@ -381,6 +385,19 @@ __global__ void __launch_bounds__(64) narrow_kernel(int npairs, const int *pi, c
   int kept = 0;
   for (int a = 0; a < nc; ++a) {
     bool del = false;
+    for (int q = 0; q < jl.mj; ++q) {
+      const int a0 = jl.b0[q], a1 = jl.b1[q];
+      if (!((a0 == i && a1 == j) || (a0 == j && a1 == i))) continue;
+      double r0[3], r1[3];
+      mat3_vec(R + 9 * (size_t)a0, jl.data + 7 * (size_t)q, r0);
+      mat3_vec(R + 9 * (size_t)a1, jl.data + 7 * (size_t)q + 3, r1);
+      double d[3];
+      for (int k = 0; k < 3; ++k) {
+        const double jp = ((pos[3 * (size_t)a0 + k] + r0[k]) + (pos[3 * (size_t)a1 + k] + r1[k])) / 2;
+        d[k] = jp - cs[7 * a + k];
+      }
+      if (sqrt(dot3(d, d)) < 1e-6) del = true;
+    }
     for (int b = 0; b < a; ++b) {
       const double d[3] = {cs[7 * b] - cs[7 * a], cs[7 * b + 1] - cs[7 * a + 1], cs[7 * b + 2] - cs[7 * a + 2]};
       if (sqrt(dot3(d, d)) < 1e-6) del = true;
@@ -466,7 +483,9 @@ const int32_t *Collider::body0() const { return impl_->b0.p; }
 const int32_t *Collider::body1() const { return impl_->b1.p; }
 const double *Collider::data() const { return impl_->data.p; }
 
-int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside) {
+int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside, int mj,
+                  const int32_t *djb0, const int32_t *djb1, const double *djdata) {
+  const JointList jl{mj, djb0, djb1, djdata};
   Impl &I = *impl_;
   n_ground_ = 0; n_pairs_ = 0;
   if (n <= 0) return 0;
@@ -489,7 +508,7 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
     I.pi.need(C); I.pj.need(C); I.pcount.need(C); I.poff.need(C); I.blocks2.need(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
     hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, I.cand.p, I.ccount.p, I.coff.p, I.pi.p, I.pj.p);
     hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
-                       (const int *)nullptr, 0, I.pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr);
+                       (const int *)nullptr, 0, I.pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr, jl);
     P = exclusive_scan(s, C, I.pcount.p, I.poff.p, I.blocks2.p, I.flags.p + 1);
   }
   const int m = G + P;
@@ -500,13 +519,14 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
                      I.b1.p, I.data.p);
   if (C > 0)
     hipLaunchKernelGGL((narrow_kernel<true>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
-                       I.poff.p, G, (int *)nullptr, I.b0.p, I.b1.p, I.data.p);
+                       I.poff.p, G, (int *)nullptr, I.b0.p, I.b1.p, I.data.p, jl);
   HIPCHK(hipGetLastError());
   return m;
 }
 
 int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
-                    int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs) {
+                    int32_t *body0, int32_t *body1, double *data, int *n_ground, int *n_pairs, int mj,
+                    const int32_t *jb0, const int32_t *jb1, const double *jdata) {
   if (n_ground) *n_ground = 0;
   if (n_pairs) *n_pairs = 0;
   if (n <= 0) return 0;
@@ -515,8 +535,15 @@ int update_contacts(hipStream_t s, int n, const double *pos, const double *R, co
   HIPCHK(hipMemcpyAsync(dpos.p, pos, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dR.p, R, nn * 9 * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dside.p, side, nn * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+  Buf<int> djb0((size_t)mj), djb1((size_t)mj);
+  Buf<double> djdata((size_t)mj * 7);
+  if (mj > 0) {
+    HIPCHK(hipMemcpyAsync(djb0.p, jb0, (size_t)mj * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(djb1.p, jb1, (size_t)mj * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(djdata.p, jdata, (size_t)mj * 7 * sizeof(double), hipMemcpyHostToDevice, s));
+  }
   Collider col;
-  const int m = col.run(s, n, dpos.p, dR.p, dside.p);
+  const int m = col.run(s, n, dpos.p, dR.p, dside.p, mj, djb0.p, djb1.p, djdata.p);
   if (n_ground) *n_ground = col.n_ground();
   if (n_pairs) *n_pairs = col.n_pairs();
   if (m > max_contacts) throw std::invalid_argument("update_contacts: max_contacts too small (" + std::to_string(m) + " needed)");

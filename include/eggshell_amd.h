@@ -199,6 +199,18 @@ egs_status egs_update_contacts(egs_context *ctx, int32_t n_bodies,
                                int32_t *m_out, int32_t *body0, int32_t *body1,
                                double *data);
 
+/* The same with the joint-vs-contact check of CheckAndCorrectEnsembleState
+ * (ensembles.cc:296-306): a contact within 1e-6 of a joint between the same two
+ * bodies (Joint::GetConstraintPosition, joints.cc:57-75) is dropped.
+ * jb0/jb1 [m_joints], jdata [m_joints][7] = c0, c1 as in set_constraints.     */
+egs_status egs_update_contacts_joints(egs_context *ctx, int32_t n_bodies,
+                                      const double *pos, const double *R,
+                                      const double *side_lengths, int32_t m_joints,
+                                      const int32_t *jb0, const int32_t *jb1,
+                                      const double *jdata, int32_t max_contacts,
+                                      int32_t *m_out, int32_t *body0,
+                                      int32_t *body1, double *data);
+
 /* ---- the whole Ensemble::Step on the device ------------------------------
  * Ensemble::Step(dt, OPEN_DYNAMICS_ENGINE) (ensembles.cc:390-427) with the
  * sparse switch on: UpdateContacts + contact pruning, StepVelocities_ODE
