@@ -344,8 +344,8 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail) {
 bool murty_device(hipStream_t s, int n, const double *dA, const double *db, const std::vector<double> &lo,
                   const std::vector<double> &hi, bool box_fix, bool block, double *dx, double *dw, int *pivots_out,
                   std::string *msg) {
-  for (int i = 0; i < n; ++i)
-    if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
+  for (int i = 0; i < n; ++i)   // lcp.cc:161-164; the box variant also admits hi == 0 (toolkit/lcp.h:129)
+    if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(box_fix ? hi[i] >= 0 : hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
   *pivots_out = 0;
   if (n == 0) return true;
   const double p2 = std::pow(2.0, n);

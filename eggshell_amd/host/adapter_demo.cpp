@@ -125,6 +125,30 @@ int main(int argc, char **argv) {
       std::printf("dense_ok %d\n", ok ? 1 : 0);
       print_vec("dense_x", x);
       print_vec("dense_w", w);
+      // lcp::SolveLCP (toolkit/lcp.h:172-174): a 12x12 box problem with two
+      // unbounded rows, A = M^T M + I from a fixed rational pattern.
+      const int n = 12;
+      MatrixXd M(n, n), A2(n, n);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) M(i, j) = ((i * 7 + j * 13) % 17 - 8) / 9.0;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          double s = (i == j) ? 1.0 : 0.0;
+          for (int k = 0; k < n; ++k) s += M(k, i) * M(k, j);
+          A2(i, j) = s;
+        }
+      VectorXd b2(n), lo2(n), hi2(n), x2, w2;
+      for (int i = 0; i < n; ++i) {
+        b2(i) = ((i * 5) % 7 - 3) * 1.5;
+        lo2(i) = -0.25; hi2(i) = 0.5;
+      }
+      lo2(3) = -std::numeric_limits<double>::infinity(); hi2(3) = std::numeric_limits<double>::infinity();
+      lo2(8) = -__DBL_MAX__; hi2(8) = __DBL_MAX__;
+      lcp::Settings settings;
+      const bool ok2 = lcp::SolveLCP(settings, A2, b2, lo2, hi2, &x2, &w2);
+      std::printf("solvelcp_ok %d\n", ok2 ? 1 : 0);
+      print_vec("solvelcp_x", x2);
+      print_vec("solvelcp_w", w2);
     }
   } catch (const egs::Error &e) {
     std::fprintf(stderr, "egs::Error %d: %s\n", e.status, e.what());

@@ -157,6 +157,27 @@ bool MixedConstraintsSolver(const MatrixXd &A, const VectorXd &b, const ArrayXb 
                             const VectorXd &x_hi, VectorXd &x, VectorXd &w);
 }
 
+// toolkit/lcp.h:104-174 -- the "adjacent" solver family the north star names
+// (lcp::SolveLCP; not linked into eggshell).  Box LCP
+// A x = b + w with lo <= 0 <= hi; rows with lo = -inf and hi = +inf (or
+// +-DBL_MAX) are unbounded, i.e. equalities, and are eliminated by a Schur
+// complement as SolveLCP_BoxSchur does (toolkit/lcp.cc:627-747).  Differences:
+// `algorithm` selects nothing (block principal pivoting with a single-index
+// safeguard is used for both), A is NOT permuted in place, and
+// max_iterations / max_time are ignored.
+namespace lcp {
+enum Algorithm { MURTY, COTTLE_DANTZIG };
+struct Settings {
+  Algorithm algorithm = MURTY;
+  bool box_lcp = true;
+  bool schur_complement = true;
+  int max_iterations = __INT_MAX__;
+  double max_time = __DBL_MAX__;
+};
+bool SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, const VectorXd &lo, const VectorXd &hi,
+              VectorXd *x, VectorXd *w);
+}  // namespace lcp
+
 class Ensemble {  // ensembles.h:25-186
  public:
   virtual ~Ensemble();

@@ -6,6 +6,7 @@
 // are redundant; the correction J^T y is unique whenever err is consistent, and
 // the sweep converges to it.
 #include <cmath>
+#include <limits>
 
 #include "eggshell_api.h"
 
@@ -97,4 +98,28 @@ void Ensemble::PostStabilize(int max_steps) {  // ensembles.cc:624-646
     ++step_counter;
   }
   last_stabilize_steps = step_counter;
+}
+
+// ---- toolkit/lcp.h:172-174 ---------------------------------------------------
+bool lcp::SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, const VectorXd &lo, const VectorXd &hi,
+                   VectorXd *x, VectorXd *w) {
+  const int N = b.size();
+  if (A.rows() != N || A.cols() != N || !x || !w) throw egs::Error(EGS_ERR_INVALID, "dimension mismatch");
+  if (settings.box_lcp && (lo.size() != N || hi.size() != N)) throw egs::Error(EGS_ERR_INVALID, "lo/hi size");
+  const double inf = std::numeric_limits<double>::infinity();
+  VectorXd l(N), h(N);
+  ArrayXb C(N);
+  for (int i = 0; i < N; ++i) {
+    l(i) = settings.box_lcp ? lo(i) : 0.0;
+    h(i) = settings.box_lcp ? hi(i) : inf;
+    if (l(i) <= -__DBL_MAX__) l(i) = -inf;   // "infinity" is DBL_MAX or the real infinity (toolkit/lcp.h:149-150)
+    if (h(i) >= __DBL_MAX__) h(i) = inf;
+    C(i) = (l(i) == -inf && h(i) == inf) ? 1 : 0;
+  }
+  x->resize(N); w->resize(N);
+  int32_t ok = 0, pivots = 0;
+  egs_status st = egs_mixed_constraints_solve(egs::DefaultContext(), N, A.data(), b.data(), C.data(), l.data(), h.data(),
+                                              /*bounds + block pivoting*/ 3, x->data(), w->data(), &ok, &pivots);
+  if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
+  return ok != 0;
 }
