@@ -340,7 +340,15 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   }
   HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream));
   if (!(prm->tol > 0)) {
-    launch_solve(p, *prm, prm->max_iters, 0);
+    // tickets are 32-bit counters that advance by cnt per sweep: very long runs
+    // are cut into resumed launches so they cannot wrap
+    const int chunk_max = std::max(1, (int)(0xF0000000u / (uint32_t)std::max(1, p->plan.max_cnt)) - 2);
+    int done = 0;
+    do {
+      const int chunk = std::min(chunk_max, prm->max_iters - done);
+      launch_solve(p, *prm, chunk, done > 0 ? 1 : 0);
+      done += chunk;
+    } while (done < prm->max_iters);
     launch_residual(p);
     p->last_iterations = prm->max_iters;
     if (stats) {

@@ -173,6 +173,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     else if (body1[i] >= 0) pos1[i] = pos0[i];  // same body on both sides
   }
 
+  for (int b = 0; b < n_bodies; ++b) plan.max_cnt = std::max(plan.max_cnt, cnt[b]);
+
   // 3. pack whole islands into tiles, first-fit in island order; islands that
   //    exceed a tile (or whose per-body count overflows 16 bits) go global.
   std::vector<int32_t> island_tile(plan.n_islands, -1);

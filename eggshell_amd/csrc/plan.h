@@ -36,6 +36,7 @@ struct GlobalDesc {    // one per constraint of the cross-workgroup path; 24 byt
 struct Plan {
   int n = 0, m = 0, block = 256;
   int n_islands = 0, n_tiles = 0, max_slots = 1;
+  int max_cnt = 1;                    // largest per-body constraint count (ticket period)
   std::vector<LaneDesc> lanes;        // n_tiles * block
   std::vector<int32_t> tile_nslots;   // per tile, slots in use (slot 0 = world)
   std::vector<int32_t> tile_slot_off; // per tile, offset into slot_body
