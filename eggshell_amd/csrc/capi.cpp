@@ -54,16 +54,22 @@ void hip_check(hipError_t e, const char *what) {
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
-  size_t count = 0;
+  size_t count = 0, cap = 0;
+  // Grow-only: a buffer that is already large enough is kept (a world re-plans
+  // on every contact-topology change; hipMalloc/hipFree would dominate that).
   void alloc(size_t n) {
-    release();
+    if (n > cap) {
+      const size_t want = p ? n + n / 4 : n;   // head-room only once a buffer has had to grow
+      release();
+      HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T)));
+      cap = want;
+    }
     count = n;
-    if (n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
   }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
-    count = 0;
+    count = cap = 0;
   }
   ~DevBuf() { release(); }
 };
@@ -75,12 +81,21 @@ void upload(DevBuf<T> &d, const T *src, size_t n, hipStream_t s) {
   HIPCHK(hipStreamSynchronize(s));  // src may be a temporary
 }
 
+// alloc + copy without the synchronise: the caller keeps src alive until it syncs
+template <typename T>
+void stage(DevBuf<T> &d, const std::vector<T> &src, hipStream_t s) {
+  d.alloc(src.size());
+  if (!src.empty()) HIPCHK(hipMemcpyAsync(d.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
 }  // namespace
 
 struct egs_problem {
   egs_context *ctx = nullptr;
   int n = 0, m = 0, precision = EGS_F64;
-  Plan plan;
+  Plan plan;                     // 1 lane per constraint (built lazily when the quad schedule applies)
+  bool tile_plan_ready = false;
+  std::vector<int32_t> h_body0, h_body1;
   // plan
   DevBuf<LaneDesc> lanes;
   DevBuf<int32_t> tile_nslots, tile_slot_off, slot_body;
@@ -177,10 +192,13 @@ void record_kernel_event(egs_context *ctx, bool begin) {
   if (!begin) ++ctx->kev_used;
 }
 
+void ensure_tile_plan(egs_problem *p);
+
 template <typename REAL>
 void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweeps, int resume) {
   egs_context *ctx = p->ctx;
   const bool quad = p->use_quad && method != EGS_JACOBI;
+  if (!quad) ensure_tile_plan(p);
   const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 &&
                      p->plan.n_patch_tiles <= kMaxPatchTiles && p->patch_enabled;
   record_kernel_event(ctx, true);
@@ -322,9 +340,10 @@ egs_status validate_params(egs_context *ctx, const egs_solve_params *prm) {
 }
 
 void fill_stats(egs_problem *p, egs_solve_stats *st) {
-  st->n_islands = p->plan.n_islands;
-  st->n_tiles = p->use_quad ? p->planq.n_tiles : p->plan.n_tiles;
-  st->n_global = (int32_t)p->plan.global.size();
+  const Plan &pl = p->use_quad ? p->planq : p->plan;   // islands and ticket periods agree between the two
+  st->n_islands = pl.n_islands;
+  st->n_tiles = pl.n_tiles;
+  st->n_global = (int32_t)pl.global.size();
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
 }
 
@@ -342,7 +361,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   if (!(prm->tol > 0)) {
     // tickets are 32-bit counters that advance by cnt per sweep: very long runs
     // are cut into resumed launches so they cannot wrap
-    const int chunk_max = std::max(1, (int)(0xF0000000u / (uint32_t)std::max(1, p->plan.max_cnt)) - 2);
+    const int chunk_max = std::max(1, (int)(0xF0000000u / (uint32_t)std::max(1, (p->use_quad ? p->planq : p->plan).max_cnt)) - 2);
     int done = 0;
     do {
       const int chunk = std::min(chunk_max, prm->max_iters - done);
@@ -501,78 +520,119 @@ egs_status egs_kernel_time(egs_context *ctx, double *sum_ms, int64_t *launches, 
   });
 }
 
+namespace {
+
+// The 1-lane-per-constraint schedule (tile / patch / global kernels).  Built on
+// demand: a problem that runs on the quad schedule only needs it for Jacobi.
+void ensure_tile_plan(egs_problem *p) {
+  if (p->tile_plan_ready) return;
+  hipStream_t s = p->ctx->stream;
+  const int n = p->n, m = p->m;
+  {
+    const char *te = std::getenv("EGS_TILE");   // experiment knob: 64/128/256/512 constraints per tile
+    const int tile = te ? std::atoi(te) : 256;
+    p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), (tile == 64 || tile == 128 || tile == 512) ? tile : 256);
+  }
+  const Plan &pl = p->plan;
+  stage(p->lanes, pl.lanes, s);
+  stage(p->tile_nslots, pl.tile_nslots, s);
+  stage(p->tile_slot_off, pl.tile_slot_off, s);
+  stage(p->slot_body, pl.slot_body, s);
+  stage(p->gcons, pl.global, s);
+  if (pl.n_patch_tiles > 0) {
+    stage(p->p_lanes, pl.patch_lanes, s);
+    stage(p->p_tile_nslots, pl.patch_tile_nslots, s);
+    stage(p->p_tile_slot_off, pl.patch_tile_slot_off, s);
+    stage(p->p_slot_body, pl.patch_slot_body, s);
+    const char *pe = std::getenv("EGS_PATCH");
+    p->patch_enabled = !(pe && std::atoi(pe) == 0);
+  }
+  const size_t mg = pl.global.size(), rsz = p->real_size();
+  p->gB0.alloc(mg * 18 * rsz); p->gB1.alloc(mg * 18 * rsz); p->gD.alloc(mg * 9 * rsz);
+  p->gden.alloc(mg * 3 * rsz); p->gdx.alloc(mg * 3 * rsz);
+  HIPCHK(hipStreamSynchronize(s));
+  p->tile_plan_ready = true;
+}
+
+// (Re)build everything that depends on the constraint topology.  Body state
+// (pos, R, v, w, M^-1, f_ext) is kept when n is unchanged; buffers only grow.
+void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const int32_t *body1) {
+  egs_context *ctx = p->ctx;
+  const int n = p->n;
+  hipStream_t s = ctx->stream;
+  p->m = m;
+  p->h_body0.assign(body0, body0 + m);
+  p->h_body1.assign(body1, body1 + m);
+  p->tile_plan_ready = false;
+  p->use_quad = false;
+  p->have_blocks = false;
+  p->have_constraints = false;
+  p->last_iterations = 0;
+  {  // quad schedule: small problems whose islands all fit 64-constraint tiles
+    const char *env = std::getenv("EGS_QUAD");
+    const int force = env ? std::atoi(env) : -1;
+    if (m > 0 && force != 0 && (force == 1 || m <= kQuadMaxConstraints)) {
+      p->planq = build_plan(n, m, body0, body1, 64);
+      if (p->planq.global.empty()) {
+        const Plan &pq = p->planq;
+        p->use_quad = true;
+        stage(p->q_lanes, pq.lanes, s);
+        stage(p->q_tile_nslots, pq.tile_nslots, s);
+        stage(p->q_tile_slot_off, pq.tile_slot_off, s);
+        stage(p->q_slot_body, pq.slot_body, s);
+        const size_t rsz = p->real_size(), mm2 = (size_t)m;
+        p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
+      }
+    }
+  }
+  stage(p->body0, p->h_body0, s);
+  stage(p->body1, p->h_body1, s);
+  const size_t rs = p->real_size();
+  const size_t nn = (size_t)(n > 0 ? n : 1), mm = (size_t)(m > 0 ? m : 1);
+  p->kind.alloc(mm); p->data.alloc(mm * 7);
+  p->err.alloc(mm * 3);
+  p->J0.alloc(mm * 18 * rs); p->J1.alloc(mm * 18 * rs);
+  p->lo.alloc(mm * 3 * rs); p->hi.alloc(mm * 3 * rs); p->rhs.alloc(mm * 3 * rs);
+  p->x.alloc(mm * 3 * rs); p->wres.alloc(mm * 3 * rs);
+  p->is_eq.alloc(mm * 3);
+  HIPCHK(hipMemsetAsync(p->acc.p, 0, nn * 6 * rs, s));
+  HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
+  HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
+  HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!p->use_quad) ensure_tile_plan(p);
+}
+
+egs_status check_topology(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0, const int32_t *body1) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return fail(ctx, EGS_ERR_INVALID, "bad sizes / NULL topology");
+  for (int i = 0; i < m; ++i)
+    if (body0[i] >= 0 && body0[i] == body1[i])
+      return fail(ctx, EGS_ERR_INVALID, "constraint with the same body on both sides");
+  return EGS_OK;
+}
+
+}  // namespace
+
 egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0,
                               const int32_t *body1, int32_t precision, egs_problem **out) {
   if (!ctx || !out) return EGS_ERR_INVALID;
   *out = nullptr;
-  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return fail(ctx, EGS_ERR_INVALID, "bad sizes / NULL topology");
+  if (egs_status st = check_topology(ctx, n, m, body0, body1)) return st;
   if (precision != EGS_F64 && precision != EGS_F32) return fail(ctx, EGS_ERR_INVALID, "unknown precision");
-  for (int i = 0; i < m; ++i)
-    if (body0[i] >= 0 && body0[i] == body1[i])
-      return fail(ctx, EGS_ERR_INVALID, "constraint with the same body on both sides");
   egs_problem *p = new (std::nothrow) egs_problem;
   if (!p) return fail(ctx, EGS_ERR_HIP, "host allocation failed");
   p->ctx = ctx; p->n = n; p->m = m; p->precision = precision;
   egs_status st = guarded(ctx, [&]() -> egs_status {
     HIPCHK(hipSetDevice(ctx->device));
-    p->plan = build_plan(n, m, body0, body1, 256);
-    const Plan &pl = p->plan;
-    hipStream_t s = ctx->stream;
-    p->lanes.alloc(pl.lanes.size()); upload(p->lanes, pl.lanes.data(), pl.lanes.size(), s);
-    p->tile_nslots.alloc(pl.tile_nslots.size()); upload(p->tile_nslots, pl.tile_nslots.data(), pl.tile_nslots.size(), s);
-    p->tile_slot_off.alloc(pl.tile_slot_off.size()); upload(p->tile_slot_off, pl.tile_slot_off.data(), pl.tile_slot_off.size(), s);
-    p->slot_body.alloc(pl.slot_body.size()); upload(p->slot_body, pl.slot_body.data(), pl.slot_body.size(), s);
-    p->gcons.alloc(pl.global.size()); upload(p->gcons, pl.global.data(), pl.global.size(), s);
-    p->gtickets.alloc((size_t)(n > 0 ? n : 1));
-    if (pl.n_patch_tiles > 0) {
-      p->p_lanes.alloc(pl.patch_lanes.size()); upload(p->p_lanes, pl.patch_lanes.data(), pl.patch_lanes.size(), s);
-      p->p_tile_nslots.alloc(pl.patch_tile_nslots.size()); upload(p->p_tile_nslots, pl.patch_tile_nslots.data(), pl.patch_tile_nslots.size(), s);
-      p->p_tile_slot_off.alloc(pl.patch_tile_slot_off.size()); upload(p->p_tile_slot_off, pl.patch_tile_slot_off.data(), pl.patch_tile_slot_off.size(), s);
-      p->p_slot_body.alloc(pl.patch_slot_body.size()); upload(p->p_slot_body, pl.patch_slot_body.data(), pl.patch_slot_body.size(), s);
-      const char *pe = std::getenv("EGS_PATCH");
-      p->patch_enabled = !(pe && std::atoi(pe) == 0);
-    }
-    {  // quad schedule: small problems whose islands all fit 64-constraint tiles
-      const char *env = std::getenv("EGS_QUAD");
-      const int force = env ? std::atoi(env) : -1;
-      if (m > 0 && force != 0 && (force == 1 || m <= kQuadMaxConstraints)) {
-        p->planq = build_plan(n, m, body0, body1, 64);
-        if (p->planq.global.empty()) {
-          const Plan &pq = p->planq;
-          p->use_quad = true;
-          p->q_lanes.alloc(pq.lanes.size()); upload(p->q_lanes, pq.lanes.data(), pq.lanes.size(), s);
-          p->q_tile_nslots.alloc(pq.tile_nslots.size()); upload(p->q_tile_nslots, pq.tile_nslots.data(), pq.tile_nslots.size(), s);
-          p->q_tile_slot_off.alloc(pq.tile_slot_off.size()); upload(p->q_tile_slot_off, pq.tile_slot_off.data(), pq.tile_slot_off.size(), s);
-          p->q_slot_body.alloc(pq.slot_body.size()); upload(p->q_slot_body, pq.slot_body.data(), pq.slot_body.size(), s);
-          const size_t rsz = p->real_size(), mm2 = (size_t)m;
-          p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
-        }
-      }
-    }
-    {
-      const size_t mg = pl.global.size(), rsz = p->real_size();
-      p->gB0.alloc(mg * 18 * rsz); p->gB1.alloc(mg * 18 * rsz); p->gD.alloc(mg * 9 * rsz);
-      p->gden.alloc(mg * 3 * rsz); p->gdx.alloc(mg * 3 * rsz);
-    }
-    p->body0.alloc(m); upload(p->body0, body0, m, s);
-    p->body1.alloc(m); upload(p->body1, body1, m, s);
-    const size_t rs = p->real_size();
-    const size_t nn = (size_t)(n > 0 ? n : 1), mm = (size_t)(m > 0 ? m : 1);
-    p->kind.alloc(mm); p->data.alloc(mm * 7);
+    const size_t rs = p->real_size(), nn = (size_t)(n > 0 ? n : 1);
+    p->gtickets.alloc(nn);
     p->pos.alloc(nn * 3); p->R.alloc(nn * 9); p->v.alloc(nn * 3); p->w.alloc(nn * 3);
-    p->Minv_d.alloc(nn * 36); p->f_ext.alloc(nn * 6); p->err.alloc(mm * 3); p->v6.alloc(nn * 6);
+    p->Minv_d.alloc(nn * 36); p->f_ext.alloc(nn * 6); p->v6.alloc(nn * 6);
     p->res_partials.alloc(4 * kResidualBlocks);
     p->Minv_r.alloc(nn * 36 * rs);
-    p->J0.alloc(mm * 18 * rs); p->J1.alloc(mm * 18 * rs);
-    p->lo.alloc(mm * 3 * rs); p->hi.alloc(mm * 3 * rs); p->rhs.alloc(mm * 3 * rs);
-    p->x.alloc(mm * 3 * rs); p->acc.alloc(nn * 6 * rs); p->wres.alloc(mm * 3 * rs);
-    p->is_eq.alloc(mm * 3);
+    p->acc.alloc(nn * 6 * rs);
     p->error_flag.alloc(1);
-    HIPCHK(hipMemsetAsync(p->acc.p, 0, nn * 6 * rs, s));
-    HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
-    HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
-    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
-    HIPCHK(hipStreamSynchronize(s));
+    problem_set_topology(p, m, body0, body1);
     return EGS_OK;
   });
   if (st != EGS_OK) { delete p; return st; }
@@ -641,10 +701,6 @@ egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind, cons
   for (int i = 0; i < p->m; ++i)
     if (kind[i] != EGS_JOINT_BALL && kind[i] != EGS_CONTACT_BOX)
       return fail(p->ctx, EGS_ERR_INVALID, "unknown constraint kind");
-  for (int i = 0; i < p->m; ++i)
-    if (kind[i] == EGS_JOINT_BALL && p->plan.m == p->m) {
-      // a joint always has body0 (joints.h:16-22)
-    }
   return guarded(p->ctx, [&]() -> egs_status {
     upload(p->kind, kind, (size_t)p->m, p->ctx->stream);
     upload(p->data, data, (size_t)p->m * 7, p->ctx->stream);
@@ -873,23 +929,19 @@ struct egs_world {
 namespace {
 
 void world_make_problem(egs_world *w, const std::vector<int32_t> &b0, const std::vector<int32_t> &b1) {
-  egs_problem *np = nullptr;
   const int m = (int)b0.size();
-  egs_status st = egs_problem_create(w->ctx, w->n, m, b0.data(), b1.data(), w->precision, &np);
-  if (st != EGS_OK) throw HipError(std::string("world: egs_problem_create: ") + egs_last_error(w->ctx));
   hipStream_t s = w->ctx->stream;
-  if (w->prob) {  // carry the body state over, device to device
-    const size_t n = (size_t)w->n;
-    HIPCHK(hipMemcpyAsync(np->pos.p, w->prob->pos.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(np->R.p, w->prob->R.p, n * 9 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(np->v.p, w->prob->v.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(np->w.p, w->prob->w.p, n * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(np->Minv_d.p, w->prob->Minv_d.p, n * 36 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(np->f_ext.p, w->prob->f_ext.p, n * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    egs_problem_destroy(w->prob);
-    np->have_state = true;
+  if (!w->prob) {
+    egs_problem *created = nullptr;
+    egs_status st = egs_problem_create(w->ctx, w->n, m, b0.data(), b1.data(), w->precision, &created);
+    if (st != EGS_OK) throw HipError(std::string("world: egs_problem_create: ") + egs_last_error(w->ctx));
+    w->prob = created;
+  } else {  // same bodies, new constraint list: the body state stays where it is
+    if (check_topology(w->ctx, w->n, m, b0.data(), b1.data()) != EGS_OK)
+      throw std::invalid_argument(egs_last_error(w->ctx));
+    problem_set_topology(w->prob, m, b0.data(), b1.data());
   }
+  egs_problem *np = w->prob;
   // constraint kinds: joints first, then contacts; joint descriptors are static
   std::vector<int32_t> kind((size_t)(m > 0 ? m : 1), EGS_CONTACT_BOX);
   const int mj = (int)w->jb0.size();
@@ -899,8 +951,6 @@ void world_make_problem(egs_world *w, const std::vector<int32_t> &b0, const std:
     if (mj > 0) upload(np->data, w->jdata.data(), (size_t)mj * 7, s);
   }
   np->have_constraints = true;
-  np->minv_r_valid = false;
-  w->prob = np;
   w->topo_b0 = b0; w->topo_b1 = b1;
   ++w->replans;
 }

@@ -214,12 +214,22 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     const bool by_phase = !(env && std::atoi(env) == 0);
     for (int i = 0; i < m; ++i) phase[i] = by_phase ? level[i] % isl_period[cons_island[i]] : 0;
   }
+  // order by (phase, island, list index): two stable counting passes (LSD radix)
   std::vector<int32_t> order(m);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (phase[a] != phase[b]) return phase[a] < phase[b];
-    return cons_island[a] < cons_island[b];
-  });
+  {
+    std::vector<int32_t> tmp(m), head;
+    auto counting_pass = [&](const std::vector<int32_t> &key, int n_keys, const int32_t *src, int32_t *dst) {
+      head.assign((size_t)n_keys + 1, 0);
+      for (int k = 0; k < m; ++k) ++head[key[src[k]] + 1];
+      for (int k = 0; k < n_keys; ++k) head[k + 1] += head[k];
+      for (int k = 0; k < m; ++k) dst[head[key[src[k]]]++] = src[k];
+    };
+    std::iota(order.begin(), order.end(), 0);
+    int max_phase = 0;
+    for (int i = 0; i < m; ++i) max_phase = std::max(max_phase, phase[i]);
+    counting_pass(cons_island, plan.n_islands, order.data(), tmp.data());
+    counting_pass(phase, max_phase + 1, tmp.data(), order.data());
+  }
 
   LaneDesc idle{};
   idle.cidx = -1;
@@ -227,14 +237,13 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   plan.tile_nslots.assign(plan.n_tiles, 1);
   plan.tile_slot_off.assign(plan.n_tiles, 0);
   std::vector<int32_t> lane_fill(plan.n_tiles, 0);
-  std::vector<int32_t> body_slot(n_bodies, -1);
-  std::vector<std::vector<int32_t>> tile_bodies(plan.n_tiles);
+  std::vector<int32_t> body_slot(n_bodies, -1), body_tile(n_bodies, -1);
 
   auto slot_of = [&](int tile, int body) -> uint16_t {
     if (body < 0) return 0;
     if (body_slot[body] < 0) {
       body_slot[body] = plan.tile_nslots[tile]++;
-      tile_bodies[tile].push_back(body);
+      body_tile[body] = tile;
     }
     return (uint16_t)body_slot[body];
   };
@@ -256,11 +265,12 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   int off = 0;
   for (int t = 0; t < plan.n_tiles; ++t) {
     plan.tile_slot_off[t] = off;
-    plan.slot_body.push_back(-1);
-    for (int b : tile_bodies[t]) plan.slot_body.push_back(b);
     off += plan.tile_nslots[t];
     plan.max_slots = std::max(plan.max_slots, plan.tile_nslots[t]);
   }
+  plan.slot_body.assign((size_t)off, -1);   // slot 0 of every tile = the world
+  for (int b = 0; b < n_bodies; ++b)
+    if (body_tile[b] >= 0) plan.slot_body[(size_t)plan.tile_slot_off[body_tile[b]] + body_slot[b]] = b;
 
   // 4. oversize islands, in list order.
   for (int i = 0; i < m; ++i) {
