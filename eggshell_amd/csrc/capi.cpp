@@ -232,7 +232,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.spin_limit = kSpinLimit;
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
-      launch_quad_solve<REAL>(a, method, p->planq.n_tiles, ctx->stream);
+      launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
     } else {
       launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
     }
@@ -572,7 +572,10 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
     const char *env = std::getenv("EGS_QUAD");
     const int force = env ? std::atoi(env) : -1;
     if (m > 0 && force != 0 && (force == 1 || m <= kQuadMaxConstraints)) {
-      p->planq = build_plan(n, m, body0, body1, 64);
+      const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
+      const int qt = qe ? std::atoi(qe) : 0;
+      // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
+      p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 256) ? qt : kAutoQuadBlock);
       if (p->planq.global.empty()) {
         const Plan &pq = p->planq;
         p->use_quad = true;

@@ -11,7 +11,9 @@
 // each pair's contacts in the order the reference emits them.  The GPU keeps it
 // with counts + exclusive scans instead of push_back:
 //   1. ground_count / cand_kernel     per body: ground contacts; candidate j > i
-//      (bounding spheres overlap; ordered by wave ballot)
+//      (bounding spheres overlap; ordered by wave ballot).  From 2048 bodies up
+//      the candidates come from a hashed uniform grid instead of all pairs
+//      (cand_grid_kernel; same sphere test, same ascending order)
 //   2. flatten candidates (scan)      -> pair list in (i, j) order
 //   3. narrow_kernel<false>           per pair: SAT + clipping, count kept contacts
 //   4. scan, narrow_kernel<true> + ground emit  -> final arrays
@@ -21,6 +23,8 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -358,6 +362,99 @@ __global__ void __launch_bounds__(64) cand_kernel(int n, const double *pos, cons
   }
 }
 
+// ---- uniform-grid broad phase (large n) ---------------------------------------
+// Cell edge >= the largest rr of the sphere test, so a touching pair is always in
+// adjacent cells.  Bodies are binned into a hashed table (count -> scan -> fill);
+// one wavefront per body i then visits its 27 neighbour cells, keeps j > i that
+// pass the SAME sphere test as cand_kernel, and sorts the (<= 64) survivors
+// ascending -- so the candidate list, hence the contact order, is identical to
+// the all-pairs kernel's.
+constexpr int kCellClamp = 1 << 20;
+
+__device__ __forceinline__ unsigned cell_hash(int x, int y, int z) {
+  return (unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u;
+}
+
+__global__ void __launch_bounds__(1024) cell_size_kernel(int n, const double *side, double *cell) {
+  __shared__ double red[1024];
+  double r = 0.0;
+  for (int b = threadIdx.x; b < n; b += 1024) r = fmax(r, 0.5 * sqrt(dot3(side + 3 * (size_t)b, side + 3 * (size_t)b)));
+  red[threadIdx.x] = r;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) cell[0] = 2.0 * red[0] * 1.000001 + 1e-9;
+}
+
+__global__ void __launch_bounds__(256) cell_bin_kernel(int n, const double *pos, const double *cell, int table_mask,
+                                                       int *coords, int *bucket_of, int *arrival, int *tcount) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  const double c = cell[0];
+  int q[3];
+  for (int k = 0; k < 3; ++k) {
+    double f = floor(pos[3 * (size_t)b + k] / c);
+    f = fmin(fmax(f, (double)-kCellClamp), (double)kCellClamp);   // monotone, so neighbours stay neighbours
+    q[k] = (int)f;
+    coords[3 * (size_t)b + k] = q[k];
+  }
+  const int bkt = (int)(cell_hash(q[0], q[1], q[2]) & (unsigned)table_mask);
+  bucket_of[b] = bkt;
+  arrival[b] = atomicAdd(&tcount[bkt], 1);   // order inside a bucket is irrelevant: candidates are sorted later
+}
+
+__global__ void __launch_bounds__(256) cell_fill_kernel(int n, const int *bucket_of, const int *arrival, const int *toff,
+                                                        int *sorted) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < n) sorted[toff[bucket_of[b]] + arrival[b]] = b;
+}
+
+__global__ void __launch_bounds__(64) cand_grid_kernel(int n, const double *pos, const double *side, const int *coords,
+                                                       int table_mask, const int *toff, const int *tcount,
+                                                       const int *sorted, int *cand, int *count, int *overflow) {
+  __shared__ int list[KMAX];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const double ci[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+  const double ri = 0.5 * sqrt(dot3(side + 3 * (size_t)i, side + 3 * (size_t)i));
+  const int cx = coords[3 * (size_t)i], cy = coords[3 * (size_t)i + 1], cz = coords[3 * (size_t)i + 2];
+  int found = 0;
+  for (int nb = 0; nb < 27; ++nb) {
+    const int x = cx + nb % 3 - 1, y = cy + (nb / 3) % 3 - 1, z = cz + nb / 9 - 1;
+    const int bkt = (int)(cell_hash(x, y, z) & (unsigned)table_mask);
+    const int beg = toff[bkt], cnt = tcount[bkt];
+    for (int base = 0; base < cnt; base += 64) {
+      const int k = base + lane;
+      bool hit = false;
+      int j = -1;
+      if (k < cnt) {
+        j = sorted[beg + k];
+        // exact cell match: a bucket shared by two cells (hash collision) is never counted twice
+        if (j > i && coords[3 * (size_t)j] == x && coords[3 * (size_t)j + 1] == y && coords[3 * (size_t)j + 2] == z) {
+          const double d[3] = {pos[3 * (size_t)j] - ci[0], pos[3 * (size_t)j + 1] - ci[1], pos[3 * (size_t)j + 2] - ci[2]};
+          const double rj = 0.5 * sqrt(dot3(side + 3 * (size_t)j, side + 3 * (size_t)j));
+          const double rr = (ri + rj) * 1.0000001 + 1e-12;
+          hit = dot3(d, d) <= rr * rr;
+        }
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int idx = found + __popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < KMAX) list[idx] = j;
+      }
+      found += __popcll(mask);
+    }
+  }
+  __syncthreads();
+  const int nf = found < KMAX ? found : KMAX;
+  const int c = lane < nf ? list[lane] : 0x7fffffff;
+  int rank = 0;
+  for (int k = 0; k < nf; ++k) rank += (__shfl(c, k) < c) ? 1 : 0;   // candidates are distinct bodies
+  if (lane < nf) cand[(size_t)i * KMAX + rank] = c;
+  if (lane == 0) {
+    if (found > KMAX) atomicOr(overflow, 1);
+    count[i] = nf;
+  }
+}
+
 __global__ void __launch_bounds__(256) flatten_kernel(int n, const int *cand, const int *count, const int *off, int *pi,
                                                       int *pj) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -443,12 +540,17 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int n, const int *in, c
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
-int exclusive_scan(hipStream_t s, int n, const int *in, int *out, int *scratch_blocks, int *total_d) {
+void exclusive_scan_async(hipStream_t s, int n, const int *in, int *out, int *scratch_blocks, int *total_d) {
   const int nblocks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  if (n <= 0) return 0;
+  if (n <= 0) return;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1), 0, s, nblocks, scratch_blocks, total_d);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks, out);
+}
+
+int exclusive_scan(hipStream_t s, int n, const int *in, int *out, int *scratch_blocks, int *total_d) {
+  if (n <= 0) return 0;
+  exclusive_scan_async(s, n, in, out, scratch_blocks, total_d);
   int total = 0;
   HIPCHK(hipMemcpyAsync(&total, total_d, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -458,6 +560,16 @@ int exclusive_scan(hipStream_t s, int n, const int *in, int *out, int *scratch_b
 }  // namespace
 
 // ---- device-resident collider ---------------------------------------------
+namespace {
+constexpr int kGridMinBodies = 2048;   // below this the all-pairs wave scan is a single cheap launch
+bool use_grid(int n) {
+  const char *e = std::getenv("EGS_BROADPHASE");   // "grid" / "pairs" force one broad phase (tests)
+  if (e && !std::strcmp(e, "grid")) return true;
+  if (e && !std::strcmp(e, "pairs")) return false;
+  return n >= kGridMinBodies;
+}
+}  // namespace
+
 struct Collider::Impl {
   // growable device buffers
   template <typename T>
@@ -474,7 +586,8 @@ struct Collider::Impl {
     ~G() { if (p) (void)hipFree(p); }
   };
   G<int> gcount, goff, ccount, coff, cand, flags, blocks, pi, pj, pcount, poff, blocks2, b0, b1;
-  G<double> data;
+  G<int> coords, bucket_of, arrival, tcount, toff, sorted, blocks3;   // uniform grid
+  G<double> data, cell;
 };
 
 Collider::Collider() : impl_(new Impl) {}
@@ -497,7 +610,22 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
   hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos, dR, dside, (const int *)nullptr, I.gcount.p,
                      (int *)nullptr, (int *)nullptr, (double *)nullptr);
   const int G = exclusive_scan(s, n, I.gcount.p, I.goff.p, I.blocks.p, I.flags.p + 1);
-  hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.cand.p, I.ccount.p, I.flags.p);
+  if (use_grid(n)) {
+    int table = 1024;
+    while (table < 2 * n) table <<= 1;
+    I.cell.need(1); I.coords.need(nn * 3); I.bucket_of.need(nn); I.arrival.need(nn); I.sorted.need(nn);
+    I.tcount.need((size_t)table); I.toff.need((size_t)table); I.blocks3.need((size_t)table / SCAN_CHUNK + 8);
+    HIPCHK(hipMemsetAsync(I.tcount.p, 0, (size_t)table * sizeof(int), s));
+    hipLaunchKernelGGL(cell_size_kernel, dim3(1), dim3(1024), 0, s, n, dside, I.cell.p);
+    hipLaunchKernelGGL(cell_bin_kernel, dim3(gb), dim3(256), 0, s, n, dpos, I.cell.p, table - 1, I.coords.p, I.bucket_of.p,
+                       I.arrival.p, I.tcount.p);
+    exclusive_scan_async(s, table, I.tcount.p, I.toff.p, I.blocks3.p, I.flags.p + 1);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(gb), dim3(256), 0, s, n, I.bucket_of.p, I.arrival.p, I.toff.p, I.sorted.p);
+    hipLaunchKernelGGL(cand_grid_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.coords.p, table - 1, I.toff.p,
+                       I.tcount.p, I.sorted.p, I.cand.p, I.ccount.p, I.flags.p);
+  } else {
+    hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.cand.p, I.ccount.p, I.flags.p);
+  }
   const int C = exclusive_scan(s, n, I.ccount.p, I.coff.p, I.blocks.p, I.flags.p + 1);
   int overflow = 0;
   HIPCHK(hipMemcpyAsync(&overflow, I.flags.p, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -128,7 +128,7 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
 
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
                 int block) {
-  if (n_bodies < 0 || m < 0 || block <= 0 || block > 1024)
+  if (n_bodies < 0 || m < 0 || block < 0 || block > 1024)
     throw std::invalid_argument("build_plan: bad sizes");
   Plan plan;
   plan.n = n_bodies; plan.m = m; plan.block = block;
@@ -164,6 +164,12 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     ++island_size[isl];
   }
   plan.n_islands = (int)island_size.size();
+  if (block == kAutoQuadBlock) {
+    int largest = 0;
+    for (int sz : island_size) largest = std::max(largest, sz);
+    block = largest <= 64 ? 64 : 256;
+    plan.block = block;
+  }
 
   // 2. per-body rank (pos) and count (cnt) in list order.
   std::vector<int32_t> cnt(n_bodies, 0), pos0(m, 0), pos1(m, 0);

@@ -13,7 +13,10 @@
 // lanes (identical inputs, identical bits); each lane then updates its own 3
 // accumulator components in LDS.  Ordering between constraints is the same
 // per-body ticket protocol as tile_solve_kernel (see kernels.hip).
-// Tile = 64 constraints = one 256-thread workgroup.
+// Tile = 64 constraints = one 256-thread workgroup, or 256 constraints = one
+// 1024-thread workgroup when islands are larger than 64 constraints.
+#include <stdexcept>
+
 #include "kernels.h"
 
 namespace egs {
@@ -111,8 +114,9 @@ __device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
   asm volatile("ds_write_b32 %0, %1" :: "v"(tick_addr), "v"(v) : "memory");
 }
 
-template <typename REAL, int METHOD>
-__global__ void __launch_bounds__(256, 4) quad_solve_kernel(const SolveArgs<REAL> A) {
+// QT = constraints per tile; the workgroup has 4 * QT threads (64 -> 256, 256 -> 1024).
+template <typename REAL, int METHOD, int QT>
+__global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
   unsigned *s_tick = reinterpret_cast<unsigned *>(smem + (size_t)A.max_slots * 6 * sizeof(REAL));
@@ -121,14 +125,14 @@ __global__ void __launch_bounds__(256, 4) quad_solve_kernel(const SolveArgs<REAL
   const int q = tid & 3, side = q >> 1, half = q & 1;
   const int nslots = A.tile_nslots[tile];
   const int32_t *slot_body = A.slot_body + A.tile_slot_off[tile];
-  for (int s = tid; s < nslots; s += 256) {
+  for (int s = tid; s < nslots; s += 4 * QT) {
     const int body = slot_body[s];
 #pragma unroll
     for (int k = 0; k < 6; ++k) s_acc[s * 6 + k] = (A.resume && body >= 0) ? A.acc[(size_t)body * 6 + k] : REAL(0);
     s_tick[s] = 0u;
   }
 
-  const LaneDesc d = A.lanes[(size_t)tile * 64 + (tid >> 2)];
+  const LaneDesc d = A.lanes[(size_t)tile * QT + (tid >> 2)];
   const bool active = d.cidx >= 0;
   const int slot = side ? d.slot1 : d.slot0;
   const bool has = active && slot != 0;            // this lane's body is a real body
@@ -282,7 +286,7 @@ __global__ void __launch_bounds__(256, 4) quad_solve_kernel(const SolveArgs<REAL
       }
     }
   }
-  for (int s = tid + 1; s < nslots; s += 256) {
+  for (int s = tid + 1; s < nslots; s += 4 * QT) {
     const int body = slot_body[s];
 #pragma unroll
     for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
@@ -292,14 +296,21 @@ __global__ void __launch_bounds__(256, 4) quad_solve_kernel(const SolveArgs<REAL
 }  // namespace
 
 template <typename REAL>
-void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, hipStream_t s) {
+void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s) {
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
-  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1>), dim3(n_tiles), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2>), dim3(n_tiles), dim3(256), lds, s, a);
+  if (tile_size == 64) {
+    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 64>), dim3(n_tiles), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 64>), dim3(n_tiles), dim3(256), lds, s, a);
+  } else if (tile_size == 256) {
+    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256>), dim3(n_tiles), dim3(1024), lds, s, a);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256>), dim3(n_tiles), dim3(1024), lds, s, a);
+  } else {
+    throw std::invalid_argument("launch_quad_solve: tile size must be 64 or 256");
+  }
 }
 
-template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, hipStream_t);
-template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, hipStream_t);
+template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
+template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, int, hipStream_t);
 
 }  // namespace egs

@@ -1,0 +1,66 @@
+"""GPU (-m gpu): the uniform-grid broad phase ("needs a broad
+phase (uniform grid)") yields exactly the candidate pairs, hence exactly the
+contact list (order included), of the all-pairs scan and of the oracle."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from eggshell_amd import scenes
+from test_gpu_collide import reference_contacts
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ctx, monkeypatch, p, R, side=None):
+    out = {}
+    for mode in ("pairs", "grid"):
+        monkeypatch.setenv("EGS_BROADPHASE", mode)
+        out[mode] = ctx.update_contacts(p, R) if side is None else ctx.update_contacts(p, R, side=side)
+    a, b = out["pairs"], out["grid"]
+    assert len(a[0]) == len(b[0])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    return b
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_grid_equals_all_pairs_and_oracle_on_random_boxes(ctx, monkeypatch, seed):
+    """Rotated boxes scattered around the origin (negative cell coordinates,
+    several bodies per cell, empty cells)."""
+    rng = np.random.default_rng(100 + seed)
+    n = 150
+    p = rng.uniform([-1.2, -1.2, 0.0], [1.2, 1.2, 0.9], (n, 3))
+    R = Rotation.random(n, random_state=seed).as_matrix().reshape(n, 9)
+    g0, g1, gd = both(ctx, monkeypatch, p, R)
+    r0, r1, rd = reference_contacts(p, R)
+    assert np.array_equal(g0, r0) and np.array_equal(g1, r1) and np.array_equal(gd, rd)
+    assert (g0 >= 0).sum() > 30          # body-body contacts present
+
+
+def test_grid_on_piles_and_far_bodies(ctx, monkeypatch):
+    sc = scenes.box_stack(8, 8, 4, jitter=1e-3, seed=5)
+    g0, g1, gd = both(ctx, monkeypatch, sc["p"], sc["R"])
+    assert np.array_equal(g0, sc["body0"]) and np.array_equal(g1, sc["body1"]) and np.array_equal(gd, sc["data"])
+    # the same pile far from the origin, plus bodies beyond the cell-coordinate clamp
+    p = sc["p"].copy()
+    p[:, 0] += 12345.678
+    p[:, 1] -= 9876.5
+    far = np.array([[4.0e6, 0.0, 0.149], [4.0e6 + 0.29, 0.0, 0.149], [-5.0e6, 3.0e6, 0.149]])
+    p = np.vstack([p, far])
+    R = np.vstack([sc["R"], np.tile(np.eye(3).reshape(1, 9), (3, 1))])
+    g0, g1, gd = both(ctx, monkeypatch, p, R)
+    n = sc["p"].shape[0]
+    assert ((g0 == n) & (g1 == n + 1)).sum() > 0       # the two far boxes touch each other
+    assert np.array_equal(g0[(g1 < n)], sc["body0"][: (g1 < n).sum()])
+
+
+def test_grid_is_the_default_for_large_ensembles(ctx, monkeypatch):
+    """20 x 20 x 24 = 9600 bodies (above the 2048 switch-over): the default path
+    equals the analytic generator's contact list."""
+    monkeypatch.delenv("EGS_BROADPHASE", raising=False)
+    sc = scenes.box_stack(20, 20, 24)
+    g0, g1, gd = ctx.update_contacts(sc["p"], sc["R"])
+    assert len(g0) == 4 * 9600
+    assert np.array_equal(g0, sc["body0"]) and np.array_equal(g1, sc["body1"]) and np.array_equal(gd, sc["data"])
+    monkeypatch.setenv("EGS_BROADPHASE", "pairs")
+    h0, h1, hd = ctx.update_contacts(sc["p"], sc["R"])
+    assert np.array_equal(g0, h0) and np.array_equal(g1, h1) and np.array_equal(gd, hd)

@@ -207,3 +207,27 @@ def test_quad_and_single_lane_schedules_agree(ctx, method, monkeypatch):
         x32, a32, st = gpu_solve(ctx, s, rhs, 0.02, method, 20, precision=capi.F32)
         xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.02, method, max_iters=20)
         assert same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_quad_schedule_with_256_constraint_tiles(ctx, method):
+    """Islands of 65..256 constraints still run 4 lanes per constraint, in
+    1024-thread tiles; same bits as the oracle (fp64 and fp32)."""
+    rng = np.random.default_rng(41)
+    cases = [system_from_scene(scenes.concat([scenes.chain(int(k)) for k in (65, 200, 256, 3, 130, 90, 17)]))[0],
+             random_system(rng, 40, 230, world_frac=0.1)[0]]
+    for s in cases:
+        rhs = rng.uniform(-1, 1, 3 * s.m)
+        for K in (1, 7, 60):
+            x, a, st = gpu_solve(ctx, s, rhs, 0.02, method, K)
+            assert st.status == capi.OK and st.reserved == 1 and st.n_global == 0
+            xf, af, _, rf = orc.fast_iterate(s, rhs, 0.02, method, max_iters=K, tol=0.0)
+            assert same_bits(x, xf) and same_bits(a, af), K
+            assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+        assert st.n_tiles < (s.m + 63) // 64          # 256-constraint tiles, not 64
+        x, a, st = gpu_solve(ctx, s, rhs, 0.1, method, 500, tol=1e-9)
+        xf, af, it, rf = orc.fast_iterate(s, rhs, 0.1, method, max_iters=500, tol=1e-9)
+        assert st.iterations == it and same_bits(x, xf)
+        x32, a32, st = gpu_solve(ctx, s, rhs, 0.02, method, 20, precision=capi.F32)
+        xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.02, method, max_iters=20)
+        assert same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
