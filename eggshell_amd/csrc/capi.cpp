@@ -3,6 +3,8 @@
 // without a usable HIP device every entry fails with EGS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +23,36 @@
 
 using namespace egs;
 
+// Page-locked staging for host->device uploads of plan tables and device->host
+// reads of the contact topology: pageable std::vector memory makes every
+// hipMemcpyAsync a synchronous bounce through the runtime's own staging buffer.
+struct PinnedArena {
+  std::vector<std::pair<char *, size_t>> blocks;
+  size_t used = 0;   // in blocks.back()
+  void *take(size_t bytes) {
+    bytes = (bytes + 63) & ~size_t(63);
+    if (blocks.empty() || used + bytes > blocks.back().second) {
+      const size_t want = std::max(bytes, blocks.empty() ? size_t(1) << 20 : 2 * blocks.back().second);
+      char *p = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault) != hipSuccess)
+        throw std::runtime_error("hipHostMalloc failed");
+      blocks.emplace_back(p, want);
+      used = 0;
+    }
+    void *r = blocks.back().first + used;
+    used += bytes;
+    return r;
+  }
+  // call only when no copy from the arena is in flight: keeps the largest block
+  void reset() {
+    while (blocks.size() > 1) { (void)hipHostFree(blocks.front().first); blocks.erase(blocks.begin()); }
+    used = 0;
+  }
+  ~PinnedArena() { for (auto &b : blocks) (void)hipHostFree(b.first); }
+};
+
 struct egs_context {
+  PinnedArena pinned;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -81,11 +112,16 @@ void upload(DevBuf<T> &d, const T *src, size_t n, hipStream_t s) {
   HIPCHK(hipStreamSynchronize(s));  // src may be a temporary
 }
 
-// alloc + copy without the synchronise: the caller keeps src alive until it syncs
+// alloc + copy through the context's pinned arena, without a synchronise; the
+// caller synchronises before the arena is reset
 template <typename T>
-void stage(DevBuf<T> &d, const std::vector<T> &src, hipStream_t s) {
+void stage(egs_context *ctx, DevBuf<T> &d, const std::vector<T> &src) {
   d.alloc(src.size());
-  if (!src.empty()) HIPCHK(hipMemcpyAsync(d.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  if (src.empty()) return;
+  const size_t bytes = src.size() * sizeof(T);
+  void *h = ctx->pinned.take(bytes);
+  std::memcpy(h, src.data(), bytes);
+  HIPCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
 }
 
 }  // namespace
@@ -534,16 +570,16 @@ void ensure_tile_plan(egs_problem *p) {
     p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), (tile == 64 || tile == 128 || tile == 512) ? tile : 256);
   }
   const Plan &pl = p->plan;
-  stage(p->lanes, pl.lanes, s);
-  stage(p->tile_nslots, pl.tile_nslots, s);
-  stage(p->tile_slot_off, pl.tile_slot_off, s);
-  stage(p->slot_body, pl.slot_body, s);
-  stage(p->gcons, pl.global, s);
+  stage(p->ctx, p->lanes, pl.lanes);
+  stage(p->ctx, p->tile_nslots, pl.tile_nslots);
+  stage(p->ctx, p->tile_slot_off, pl.tile_slot_off);
+  stage(p->ctx, p->slot_body, pl.slot_body);
+  stage(p->ctx, p->gcons, pl.global);
   if (pl.n_patch_tiles > 0) {
-    stage(p->p_lanes, pl.patch_lanes, s);
-    stage(p->p_tile_nslots, pl.patch_tile_nslots, s);
-    stage(p->p_tile_slot_off, pl.patch_tile_slot_off, s);
-    stage(p->p_slot_body, pl.patch_slot_body, s);
+    stage(p->ctx, p->p_lanes, pl.patch_lanes);
+    stage(p->ctx, p->p_tile_nslots, pl.patch_tile_nslots);
+    stage(p->ctx, p->p_tile_slot_off, pl.patch_tile_slot_off);
+    stage(p->ctx, p->p_slot_body, pl.patch_slot_body);
     const char *pe = std::getenv("EGS_PATCH");
     p->patch_enabled = !(pe && std::atoi(pe) == 0);
   }
@@ -560,6 +596,8 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   egs_context *ctx = p->ctx;
   const int n = p->n;
   hipStream_t s = ctx->stream;
+  HIPCHK(hipStreamSynchronize(s));   // nothing may still read the pinned arena
+  ctx->pinned.reset();
   p->m = m;
   p->h_body0.assign(body0, body0 + m);
   p->h_body1.assign(body1, body1 + m);
@@ -579,17 +617,17 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
       if (p->planq.global.empty()) {
         const Plan &pq = p->planq;
         p->use_quad = true;
-        stage(p->q_lanes, pq.lanes, s);
-        stage(p->q_tile_nslots, pq.tile_nslots, s);
-        stage(p->q_tile_slot_off, pq.tile_slot_off, s);
-        stage(p->q_slot_body, pq.slot_body, s);
+        stage(p->ctx, p->q_lanes, pq.lanes);
+        stage(p->ctx, p->q_tile_nslots, pq.tile_nslots);
+        stage(p->ctx, p->q_tile_slot_off, pq.tile_slot_off);
+        stage(p->ctx, p->q_slot_body, pq.slot_body);
         const size_t rsz = p->real_size(), mm2 = (size_t)m;
         p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
       }
     }
   }
-  stage(p->body0, p->h_body0, s);
-  stage(p->body1, p->h_body1, s);
+  stage(p->ctx, p->body0, p->h_body0);
+  stage(p->ctx, p->body1, p->h_body1);
   const size_t rs = p->real_size();
   const size_t nn = (size_t)(n > 0 ? n : 1), mm = (size_t)(m > 0 ? m : 1);
   p->kind.alloc(mm); p->data.alloc(mm * 7);
@@ -924,25 +962,30 @@ struct egs_world {
   DevBuf<int32_t> djb0, djb1;          // the same on the device, for joint-vs-contact pruning
   DevBuf<double> djdata;
   std::vector<int32_t> topo_b0, topo_b1;
+  PinnedArena topo_pinned;             // page-locked landing area for the contact topology
+  int32_t *h_b0 = nullptr, *h_b1 = nullptr;
+  size_t h_cap = 0;
   int m_contacts = 0;
   int replans = 0;
   bool have_bodies = false;
+  // EGS_WORLD_TRACE=1: host wall time per phase of egs_world_step, printed by egs_world_destroy
+  bool trace = false;
+  double t_phase[5] = {0, 0, 0, 0, 0};   // collide, topology D2H + compare, re-plan, solve + integrate (enqueue), steps
 };
 
 namespace {
 
-void world_make_problem(egs_world *w, const std::vector<int32_t> &b0, const std::vector<int32_t> &b1) {
-  const int m = (int)b0.size();
+void world_make_problem(egs_world *w, const int32_t *b0, const int32_t *b1, int m) {
   hipStream_t s = w->ctx->stream;
   if (!w->prob) {
     egs_problem *created = nullptr;
-    egs_status st = egs_problem_create(w->ctx, w->n, m, b0.data(), b1.data(), w->precision, &created);
+    egs_status st = egs_problem_create(w->ctx, w->n, m, b0, b1, w->precision, &created);
     if (st != EGS_OK) throw HipError(std::string("world: egs_problem_create: ") + egs_last_error(w->ctx));
     w->prob = created;
   } else {  // same bodies, new constraint list: the body state stays where it is
-    if (check_topology(w->ctx, w->n, m, b0.data(), b1.data()) != EGS_OK)
+    if (check_topology(w->ctx, w->n, m, b0, b1) != EGS_OK)
       throw std::invalid_argument(egs_last_error(w->ctx));
-    problem_set_topology(w->prob, m, b0.data(), b1.data());
+    problem_set_topology(w->prob, m, b0, b1);
   }
   egs_problem *np = w->prob;
   // constraint kinds: joints first, then contacts; joint descriptors are static
@@ -954,7 +997,7 @@ void world_make_problem(egs_world *w, const std::vector<int32_t> &b0, const std:
     if (mj > 0) upload(np->data, w->jdata.data(), (size_t)mj * 7, s);
   }
   np->have_constraints = true;
-  w->topo_b0 = b0; w->topo_b1 = b1;
+  w->topo_b0.assign(b0, b0 + m); w->topo_b1.assign(b1, b1 + m);
   ++w->replans;
 }
 
@@ -969,6 +1012,7 @@ egs_status egs_world_create(egs_context *ctx, int32_t n_bodies, int32_t precisio
   egs_world *w = new (std::nothrow) egs_world;
   if (!w) return fail(ctx, EGS_ERR_HIP, "host allocation failed");
   w->ctx = ctx; w->n = n_bodies; w->precision = precision;
+  { const char *te = std::getenv("EGS_WORLD_TRACE"); w->trace = te && std::atoi(te) != 0; }
   egs_status st = guarded(ctx, [&]() -> egs_status {
     HIPCHK(hipSetDevice(ctx->device));
     w->dside.alloc((size_t)(n_bodies > 0 ? n_bodies : 1) * 3);
@@ -981,6 +1025,11 @@ egs_status egs_world_create(egs_context *ctx, int32_t n_bodies, int32_t precisio
 
 void egs_world_destroy(egs_world *w) {
   if (!w) return;
+  if (w->trace && w->t_phase[4] > 0) {
+    const double k = 1.0 / w->t_phase[4];
+    std::fprintf(stderr, "egs_world trace (%d steps, %d re-plans), us/step: collide %.1f  topology %.1f  re-plan %.1f  solve+integrate %.1f\n",
+                 (int)w->t_phase[4], w->replans, w->t_phase[0] * k, w->t_phase[1] * k, w->t_phase[2] * k, w->t_phase[3] * k);
+  }
   if (w->prob) egs_problem_destroy(w->prob);
   delete w;
 }
@@ -991,7 +1040,7 @@ egs_status egs_world_set_bodies(egs_world *w, const double *pos, const double *R
   if (w->n > 0 && (!pos || !R || !v || !wv || !Minv || !f_ext || !side_lengths))
     return fail(w->ctx, EGS_ERR_INVALID, "NULL array");
   return guarded(w->ctx, [&]() -> egs_status {
-    if (!w->prob) world_make_problem(w, w->jb0, w->jb1);
+    if (!w->prob) world_make_problem(w, w->jb0.data(), w->jb1.data(), (int)w->jb0.size());
     egs_status st = egs_problem_set_state(w->prob, pos, R, v, wv, Minv, f_ext);
     if (st != EGS_OK) return st;
     upload(w->dside, side_lengths, (size_t)w->n * 3, w->ctx->stream);
@@ -1013,8 +1062,7 @@ egs_status egs_world_set_joints(egs_world *w, int32_t m_joints, const int32_t *b
       upload(w->djb1, body1, (size_t)m_joints, w->ctx->stream);
       upload(w->djdata, data, (size_t)m_joints * 7, w->ctx->stream);
     }
-    std::vector<int32_t> b0 = w->jb0, b1 = w->jb1;   // contacts are re-detected by the next step
-    world_make_problem(w, b0, b1);
+    world_make_problem(w, w->jb0.data(), w->jb1.data(), m_joints);   // contacts are re-detected by the next step
     w->m_contacts = 0;
     return EGS_OK;
   });
@@ -1028,16 +1076,36 @@ egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_p
   return guarded(w->ctx, [&]() -> egs_status {
     hipStream_t s = w->ctx->stream;
     const int mj = (int)w->jb0.size();
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    auto lap = [&](int k) {
+      if (!w->trace) return;
+      const auto t1 = clk::now();
+      w->t_phase[k] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+      t0 = t1;
+    };
     if (detect_contacts) {  // UpdateContacts + pruning on the device (ensembles.cc:393-394)
       const int mc = w->col.run(s, w->n, w->prob->pos.p, w->prob->R.p, w->dside.p, mj, w->djb0.p, w->djb1.p, w->djdata.p);
-      std::vector<int32_t> b0(w->jb0), b1(w->jb1);
-      b0.resize((size_t)mj + mc); b1.resize((size_t)mj + mc);
-      if (mc > 0) {
-        HIPCHK(hipMemcpyAsync(b0.data() + mj, w->col.body0(), (size_t)mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(b1.data() + mj, w->col.body1(), (size_t)mc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      lap(0);
+      const size_t mt = (size_t)mj + (size_t)mc;
+      if (mt > w->h_cap) {   // grow-only; the stream is idle here (col.run synchronised)
+        w->topo_pinned.reset();
+        w->h_cap = mt + mt / 4 + 64;
+        w->h_b0 = static_cast<int32_t *>(w->topo_pinned.take(2 * w->h_cap * sizeof(int32_t)));
+        w->h_b1 = w->h_b0 + w->h_cap;
+      }
+      std::copy(w->jb0.begin(), w->jb0.end(), w->h_b0);
+      std::copy(w->jb1.begin(), w->jb1.end(), w->h_b1);
+      if (mc > 0) {   // the GPU writes the 8 bytes per contact straight into page-locked host memory
+        w->col.export_topology(s, mc, w->h_b0 + mj, w->h_b1 + mj);
         HIPCHK(hipStreamSynchronize(s));
       }
-      if (b0 != w->topo_b0 || b1 != w->topo_b1) world_make_problem(w, b0, b1);  // host plan only on topology change
+      const bool changed = mt != w->topo_b0.size() || (mt > 0 && (
+                           std::memcmp(w->h_b0, w->topo_b0.data(), mt * sizeof(int32_t)) != 0 ||
+                           std::memcmp(w->h_b1, w->topo_b1.data(), mt * sizeof(int32_t)) != 0));
+      lap(1);
+      if (changed) world_make_problem(w, w->h_b0, w->h_b1, (int)mt);  // host plan only on topology change
+      lap(2);
       if (mc > 0)
         HIPCHK(hipMemcpyAsync(w->prob->data.p + (size_t)mj * 7, w->col.data(), (size_t)mc * 7 * sizeof(double),
                               hipMemcpyDeviceToDevice, s));
@@ -1056,6 +1124,7 @@ egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_p
     do_velocity(p, dt);
     launch_advance(p->n, p->pos.p, p->R.p, p->v.p, p->w.p, p->v6.p, dt, s);
     HIPCHK(hipGetLastError());
+    if (w->trace) { HIPCHK(hipStreamSynchronize(s)); lap(3); w->t_phase[4] += 1; }
     return EGS_OK;
   });
 }

@@ -27,6 +27,8 @@ class Collider {
   // joint between the same two bodies are dropped (ensembles.cc:296-306)
   int run(hipStream_t s, int n, const double *dpos, const double *dR, const double *dside, int mj = 0,
           const int32_t *djb0 = nullptr, const int32_t *djb1 = nullptr, const double *djdata = nullptr);  // returns m
+  // body0()/body1() of the last run() written to device-visible host memory (hipHostMalloc)
+  void export_topology(hipStream_t s, int m, int32_t *mapped_b0, int32_t *mapped_b1) const;
   const int32_t *body0() const;
   const int32_t *body1() const;
   const double *data() const;

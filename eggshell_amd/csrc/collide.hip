@@ -510,6 +510,13 @@ __global__ void __launch_bounds__(64) narrow_kernel(int npairs, const int *pi, c
   if (!EMIT) count[t] = kept;
 }
 
+// Copies the contact topology into device-visible (page-locked host) memory: a
+// small PCIe write by the GPU is far cheaper than two DMA-engine copies.
+__global__ void __launch_bounds__(256) export_pairs_kernel(int m, const int *b0, const int *b1, int *o0, int *o1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) { o0[i] = b0[i]; o1[i] = b1[i]; }
+}
+
 // ---- exclusive scan (int32), three small kernels ----------------------------
 constexpr int SCAN_CHUNK = 2048;  // elements per block (256 threads x 8)
 __global__ void __launch_bounds__(256) scan_reduce_kernel(int n, const int *in, int *block_sums) {
@@ -650,6 +657,13 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
                        I.poff.p, G, (int *)nullptr, I.b0.p, I.b1.p, I.data.p, jl);
   HIPCHK(hipGetLastError());
   return m;
+}
+
+void Collider::export_topology(hipStream_t s, int m, int32_t *mapped_b0, int32_t *mapped_b1) const {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(export_pairs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, m, impl_->b0.p, impl_->b1.p, mapped_b0,
+                     mapped_b1);
+  HIPCHK(hipGetLastError());
 }
 
 int update_contacts(hipStream_t s, int n, const double *pos, const double *R, const double *side, int max_contacts,
