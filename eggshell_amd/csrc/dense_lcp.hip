@@ -37,7 +37,6 @@ namespace egs {
 namespace {
 
 constexpr int NB = 64;    // block size = wavefront size
-constexpr int LDP = 65;   // padded LDS row stride (doubles): conflict-free column walks
 
 struct HipErr : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -50,45 +49,119 @@ void chk(hipError_t e, const char *what) {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---- blocked Cholesky ------------------------------------------------------
-// One wavefront per 64-row slab of the panel T[k0.., k0..k0+64).  Every
-// workgroup factors the diagonal block itself (in LDS; same arithmetic, so the
-// copies agree bit for bit); slab 0 writes L back, slab s > 0 solves
-// X L^T = B for its rows.  Lane i owns row i of the block / slab.
-__global__ void __launch_bounds__(64) chol_panel_kernel(double *T, int ld, int nrows, int k0, int *fail) {
-  __shared__ double sL[NB * LDP];
-  __shared__ double sX[NB * LDP];
-  const int lane = threadIdx.x;
-  const int slab = blockIdx.x;
-  for (int c = 0; c < NB; ++c) sL[lane * LDP + c] = (c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
-  __syncthreads();
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(d) to within an ulp or two: hardware estimate y, e = 1 - d y^2, then
+// y (1 + e/2 + 3 e^2 / 8) (cubic convergence, one short dependent chain).
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-d * y, y, 1.0);
+  const double t = __builtin_fma(0.375, e, 0.5) * e;
+  return __builtin_fma(y, t, y);
+}
+
+// Diagonal block: L11 = chol(T[k0.., k0..+64)) and its inverse, one workgroup of
+// two wavefronts in lock step (one barrier per column), everything in registers:
+//   wavefront 0, lane i = row i of the block: right-looking Cholesky; column j,
+//     scaled by 1/sqrt(pivot), is published in LDS as soon as it is final;
+//   wavefront 1, lane c = column c of L11^-1: forward substitution L X = I fed
+//     by those columns (row j of the inverse is complete after step j).
+// Both read the published column into registers first (LDS broadcasts, issued
+// back to back) and then run their 63-j fused multiply-adds.
+// The inverse turns the panel's triangular solve and the diagonal steps of the
+// back substitution into matrix products (chol_trsm_kernel, back_solve_kernel).
+__global__ void __launch_bounds__(128) chol_diag_kernel(double *T, int ld, int k0, double *inv, int *fail) {
+  __shared__ __attribute__((aligned(16))) double sCol[2][NB];
+  __shared__ double sRinv[2];
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = (role == 0 && c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
+  bool bad = false;
+#pragma unroll
   for (int j = 0; j < NB; ++j) {
-    double s = 0.0;
-    if (lane >= j) {
-      s = sL[lane * LDP + j];
-      for (int k = 0; k < j; ++k) s = __builtin_fma(-sL[lane * LDP + k], sL[j * LDP + k], s);
-    }
-    if (lane == j) {
-      if (!(s > 0.0)) { atomicOr(fail, 1); s = 1.0; }
-      sL[j * LDP + j] = sqrt(s);
+    if (role == 0) {
+      double d = readlane_f64(a[j], j);
+      if (!(d > 0.0)) { bad = true; d = 1.0; }
+      const double rinv = rsqrt_refined(d);
+      const double l = (lane >= j) ? a[j] * rinv : 0.0;
+      a[j] = l;
+      sCol[j & 1][lane] = l;
+      if (lane == j) sRinv[j & 1] = rinv;
     }
     __syncthreads();
-    if (lane > j) sL[lane * LDP + j] = s / sL[j * LDP + j];
-    __syncthreads();
+    double col[NB];
+#pragma unroll
+    for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
+    if (role == 0) {
+      const double l = a[j];
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(-l, col[k], a[k]);
+    } else {
+      const double xj = (((lane == j) ? 1.0 : 0.0) - a[j]) * sRinv[j & 1];   // lanes c > j: exactly 0
+      inv[j * NB + lane] = xj;
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(col[k], xj, a[k]);
+    }
   }
-  if (slab == 0) {
-    for (int c = 0; c <= lane; ++c) T[(size_t)(k0 + lane) * ld + k0 + c] = sL[lane * LDP + c];
-    return;
+  if (role == 0) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c <= lane) T[(size_t)(k0 + lane) * ld + k0 + c] = a[c];
+    if (bad && lane == 0) atomicOr(fail, 1);
   }
-  const int row = k0 + slab * NB + lane;
-  const bool live = row < nrows;
-  for (int c = 0; c < NB; ++c) sX[lane * LDP + c] = live ? T[(size_t)row * ld + k0 + c] : 0.0;
-  for (int j = 0; j < NB; ++j) {
-    double s = sX[lane * LDP + j];
-    for (int k = 0; k < j; ++k) s = __builtin_fma(-sX[lane * LDP + k], sL[j * LDP + k], s);
-    sX[lane * LDP + j] = s / sL[j * LDP + j];
+}
+
+// Panel below the diagonal block: X = B L11^-T = B (L11^-1)^T on the fp64 matrix
+// cores, X[r][c] = sum_k B[r][k] Linv[c][k].  One workgroup per 64-row slab,
+// each wavefront a 32x32 quadrant (operand maps as in chol_update_kernel).
+__global__ void __launch_bounds__(256) chol_trsm_kernel(double *T, int ld, int nrows, int k0, const double *inv) {
+  const int r0 = k0 + NB + blockIdx.x * NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qr = r0 + (wave >> 1) * 32, qc = (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const double *Pa[2], *Pb[2];
+  bool va[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ra = qr + 16 * t + li;
+    va[t] = ra < nrows;
+    Pa[t] = T + (size_t)(va[t] ? ra : 0) * ld + k0;
+    Pb[t] = inv + (size_t)(qc + 16 * t + li) * NB;
   }
-  if (live)
-    for (int c = 0; c < NB; ++c) T[(size_t)row * ld + k0 + c] = sX[lane * LDP + c];
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    double a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = va[t] ? Pa[t][4 * kk + lk] : 0.0;
+      b[t] = Pb[t][4 * kk + lk];
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+  }
+  __syncthreads();   // every wavefront has read its rows of B before anyone overwrites them
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
+        if (r < nrows) T[(size_t)r * ld + k0 + c] = acc[ti][tj][reg];
+      }
 }
 
 // Trailing update on the fp64 matrix cores: for rows r >= k0+64 and columns
@@ -118,7 +191,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
     Pa[t] = T + (size_t)(va[t] ? ra : 0) * ld + k0;
     Pb[t] = T + (size_t)(vb[t] ? rb : 0) * ld + k0;
   }
-#pragma unroll 4
+#pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
     double a[2], b[2];
 #pragma unroll
@@ -143,39 +216,68 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
       }
 }
 
-// Solve L^T x = y in one workgroup: L = T[0..nf)[0..nf) lower, y = T[yrow][0..nf).
+// Solve L^T x = y in one workgroup: L = T[0..nf)[0..nf) lower, y = T[yrow][0..nf),
+// inv = the L_kk^-1 blocks chol_diag_kernel left behind.  Blocks from the last to
+// the first: x_k = L_kk^-T t_k is a 64x64 product with the stored inverse, then
+// the 64-row strip L[k-block][0..k) (contiguous rows, coalesced) is subtracted
+// from the remaining right-hand side.
 // x is written to out[map ? map[i] : i] for i < nreal (padding rows dropped).
-__global__ void __launch_bounds__(256) back_solve_kernel(const double *T, int ld, int nf, int yrow, int nreal,
-                                                         const int *map, double *out, double *xs /*[nf] scratch*/) {
+__global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int ld, int nf, int yrow, int nreal,
+                                                          const int *map, double *out, double *xs /*[nf] scratch*/,
+                                                          const double *inv) {
   __shared__ double sx[NB];
-  __shared__ double red[256];
+  __shared__ double red[16][NB];
   const int tid = threadIdx.x;
-  for (int i = tid; i < nf; i += 256) xs[i] = T[(size_t)yrow * ld + i];
+  for (int i = tid; i < nf; i += 1024) xs[i] = T[(size_t)yrow * ld + i];
   __syncthreads();
   for (int kb = nf - NB; kb >= 0; kb -= NB) {
-    // t_i = y_i - sum_{r >= kb+64} L[r][kb+i] x_r   (i = 0..63), 4 threads per i
+    const double *Li = inv + (size_t)(kb / NB) * NB * NB;
     const int i = tid & 63, part = tid >> 6;
     double s = 0.0;
-    for (int r = kb + NB + part; r < nf; r += 4) s = __builtin_fma(T[(size_t)r * ld + kb + i], xs[r], s);
-    red[tid] = s;
+#pragma unroll
+    for (int r = part; r < NB; r += 16) s = __builtin_fma(Li[r * NB + i], xs[kb + r], s);   // Linv[r][i] = 0 for i > r
+    red[part][i] = s;
     __syncthreads();
-    if (tid < NB) sx[tid] = xs[kb + tid] - ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]));
-    __syncthreads();
-    // back substitution inside the 64x64 diagonal block (wavefront 0)
     if (tid < NB) {
-      for (int j = NB - 1; j >= 0; --j) {
-        if (tid == j) sx[j] = sx[j] / T[(size_t)(kb + j) * ld + kb + j];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (tid < j) sx[tid] = __builtin_fma(-T[(size_t)(kb + j) * ld + kb + tid], sx[j], sx[tid]);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      }
-      xs[kb + tid] = sx[tid];
+      double x = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) x += red[p][tid];
+      sx[tid] = x;
+      xs[kb + tid] = x;
+    }
+    __syncthreads();
+    for (int c = tid; c < kb; c += 1024) {
+      double y = xs[c];
+#pragma unroll 32
+      for (int r = 0; r < NB; ++r) y = __builtin_fma(-T[(size_t)(kb + r) * ld + c], sx[r], y);
+      xs[c] = y;
     }
     __syncthreads();
   }
-  for (int i = tid; i < nreal; i += 256) out[map ? map[i] : i] = xs[i];
+  for (int i = tid; i < nreal; i += 1024) out[map ? map[i] : i] = xs[i];
+}
+
+// max |a_ij| and max |a_ij - a_ji| over i > j (non-negative doubles order like
+// their bit patterns, so an integer atomicMax does the reduction).
+__global__ void __launch_bounds__(256) symmetry_kernel(const double *A, int N, unsigned long long *out /*[2]*/) {
+  double amax = 0.0, asym = 0.0;
+  const size_t total = (size_t)N * N;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int i = (int)(idx / N), j = (int)(idx % N);
+    if (j < i) {
+      const double v = A[idx];
+      amax = fmax(amax, fabs(v));
+      asym = fmax(asym, fabs(v - A[(size_t)j * N + i]));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    amax = fmax(amax, __shfl_down(amax, o, 64));
+    asym = fmax(asym, __shfl_down(asym, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(amax));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(asym));
+  }
 }
 
 // ---- gathers ---------------------------------------------------------------
@@ -322,11 +424,14 @@ inline int grid1(size_t n, int block = 256) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
-// Blocked Cholesky of the first nf (multiple of 64) columns of T.
-void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail) {
+// Blocked Cholesky of the first nf (multiple of 64) columns of T; inv receives
+// the nf/64 inverted diagonal blocks (64x64 each).
+void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
   for (int k0 = 0; k0 < nf; k0 += NB) {
-    const int slabs = (nrows - k0 + NB - 1) / NB;
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(slabs), dim3(64), 0, s, T, ld, nrows, k0, fail);
+    double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, s, T, ld, k0, inv_k, fail);
+    const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
+    if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, ld, nrows, k0, inv_k);
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
     if (tr > 0 && tc > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tc, tr), dim3(256), 0, s, T, ld, nrows, k0);
   }
@@ -351,7 +456,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   const double p2 = std::pow(2.0, n);
   const int max_iterations = block ? 4 * n + 100 : (p2 > 1000 ? 1000 : (int)p2);  // lcp.cc:168
   const int npad_max = (n + NB - 1) / NB * NB;
-  Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max);
+  Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
   Buf<uint8_t> S_d(n);
   Buf<int> idx_d(n), fail_d(1);
   Buf<MurtyRecord> rec_d(1);
@@ -448,8 +553,9 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
       HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), ns * sizeof(int), hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
                          nspad, beff.p, T.p);
-      factor(s, T.p, nspad, nspad + 1, nspad, fail_d.p);
-      hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(256), 0, s, T.p, nspad, nspad, nspad, ns, idx_d.p, dx, xs.p);
+      factor(s, T.p, nspad, nspad + 1, nspad, fail_d.p, dinv.p);
+      hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, nspad, nspad, nspad, ns, idx_d.p, dx, xs.p,
+                         dinv.p);
     }
     // r = A x - b; w(!S) = r (box_fix) or A(!S,S) x(S) - b(!S) (reference, lcp.cc:219-221)
     if (box_fix) {
@@ -496,28 +602,33 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
                              std::string *msg) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
-  double amax = 0, asym = 0;
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < i; ++j) {
-      amax = std::max(amax, std::fabs(A[(size_t)i * N + j]));
-      asym = std::max(asym, std::fabs(A[(size_t)i * N + j] - A[(size_t)j * N + i]));
-    }
-  if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
   std::vector<int> E, I;
   for (int i = 0; i < N; ++i) (C[i] ? E : I).push_back(i);
   const int ne = (int)E.size(), ni = (int)I.size();
   const int nepad = (ne + NB - 1) / NB * NB;
   const int ld = nepad + ni, rows = nepad + ni + 1;
-  Buf<double> dA((size_t)N * N), db(N), T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad);
+  Buf<double> dA((size_t)N * N), db(N), T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad), dinv((size_t)nepad * NB);
   Buf<int> dE(ne), dI(ni), fail_d(1);
   HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
   if (ne) HIPCHK(hipMemcpyAsync(dE.p, E.data(), ne * sizeof(int), hipMemcpyHostToDevice, s));
   if (ni) HIPCHK(hipMemcpyAsync(dI.p, I.data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  {  // A must be symmetric: the factorisations read its lower triangle only
+    Buf<unsigned long long> sym_d(2);
+    unsigned long long sym_h[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(symmetry_kernel, dim3(grid1((size_t)N * N)), dim3(256), 0, s, dA.p, N, sym_d.p);
+    HIPCHK(hipMemcpyAsync(sym_h, sym_d.p, sizeof sym_h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double amax, asym;
+    std::memcpy(&amax, &sym_h[0], sizeof amax);
+    std::memcpy(&asym, &sym_h[1], sizeof asym);
+    if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
+  }
   // Schur stage: factor the E columns of [A_ee A_ei; A_ie A_ii; b^T]   (lcp.cc:286-294)
   hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE.p, ne, nepad, dI.p, ni, T.p);
-  factor(s, T.p, ld, rows, nepad, fail_d.p);
+  factor(s, T.p, ld, rows, nepad, fail_d.p, dinv.p);
   if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
   int fail = 0;
   HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -534,7 +645,8 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   std::vector<double> xih(ni), wih(ni), xeh(ne);
   if (ne) {
     hipLaunchKernelGGL(xe_rhs_kernel, dim3((nepad + 255) / 256), dim3(256), 0, s, T.p, nepad, ni, xi.p);
-    hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(256), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p);
+    hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p,
+                       dinv.p);
     HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (ni) {
