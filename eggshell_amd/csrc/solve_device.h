@@ -235,6 +235,43 @@ __device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0,
   a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
   a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
 }
+// two-stage variant: tickets only (8 bytes per lane instead of 104) ...
+__device__ __forceinline__ void poll_ticks(unsigned tk0, unsigned tk1, unsigned &t0, unsigned &t1) {
+  asm volatile(
+      "ds_read_b32 %0, %2\n\t"
+      "ds_read_b32 %1, %3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0), "=&v"(t1) : "v"(tk0), "v"(tk1) : "memory");
+}
+// ... then the accumulators of the lanes whose turn it is
+__device__ __forceinline__ void load12(unsigned ac0, unsigned ac1, double (&a0)[6], double (&a1)[6]) {
+  d2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b128 %0, %6\n\t"
+      "ds_read_b128 %1, %6 offset:16\n\t"
+      "ds_read_b128 %2, %6 offset:32\n\t"
+      "ds_read_b128 %3, %7\n\t"
+      "ds_read_b128 %4, %7 offset:16\n\t"
+      "ds_read_b128 %5, %7 offset:32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(ac0), "v"(ac1) : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
+__device__ __forceinline__ void load12(unsigned ac0, unsigned ac1, float (&a0)[6], float (&a1)[6]) {
+  f2_t u0, u1, u2, v0, v1, v2;
+  asm volatile(
+      "ds_read_b64 %0, %6\n\t"
+      "ds_read_b64 %1, %6 offset:8\n\t"
+      "ds_read_b64 %2, %6 offset:16\n\t"
+      "ds_read_b64 %3, %7\n\t"
+      "ds_read_b64 %4, %7 offset:8\n\t"
+      "ds_read_b64 %5, %7 offset:16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(ac0), "v"(ac1) : "memory");
+  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
+  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
+}
 __device__ __forceinline__ void store6(unsigned ac, const double (&a)[6]) {
   d2_t u0 = {a[0], a[1]}, u1 = {a[2], a[3]}, u2 = {a[4], a[5]};
   asm volatile(
