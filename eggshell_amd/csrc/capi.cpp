@@ -568,12 +568,19 @@ void ensure_tile_plan(egs_problem *p) {
   {
     // 256 constraints per tile; 512 once there are enough tiles to give every CU two
     // anyway (all 64 lanes of the working wavefront busy: +3-4 % on 16 batched C3 piles).
-    // Oversize islands (patch / global kernels) always use 256.
+    // Oversize islands (patch / global kernels) always use 256 -- unless 512 makes every island fit.
     const char *te = std::getenv("EGS_TILE");   // experiment knob: 64/128/256/512 constraints per tile
     const int forced = te ? std::atoi(te) : 0;
     int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints ? 512 : 256);
     p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), tile);
-    if (tile != 256 && !p->plan.global.empty()) p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), 256);
+    if (!forced && !p->plan.global.empty()) {
+      if (tile == 256) {   // islands of 257..512 constraints: one 512-thread workgroup, all hand-offs in LDS
+        Plan big = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), 512);
+        if (big.global.empty()) p->plan = std::move(big);
+      } else {
+        p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), 256);
+      }
+    }
   }
   const Plan &pl = p->plan;
   stage(p->ctx, p->lanes, pl.lanes);

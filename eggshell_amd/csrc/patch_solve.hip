@@ -67,11 +67,12 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
     unsigned g0 = want0, g1 = want1;
     if (sh0) g0 = gld(gt0);
     if (sh1) g1 = gld(gt1);
-    poll12(tk0, tk1, ac0, ac1, t0, t1, a0, a1);
+    poll_ticks(tk0, tk1, t0, t1);   // tickets first, accumulators only when it is this lane's turn (see kernels.hip)
     if (sh0) t0 = g0;
     if (sh1) t1 = g1;
     const bool ready = (!has0 || t0 == want0) && (!has1 || t1 == want1);
     if (ready) {
+      load12(ac0, ac1, a0, a1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (sh0) {
 #pragma unroll
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
       }
       if (has0) { if (sh0) gst(gt0, want0 + 1u); else store_tick(tk0, want0 + 1u); }
       if (has1) { if (sh1) gst(gt1, want1 + 1u); else store_tick(tk1, want1 + 1u); }
+      asm volatile("s_wakeup");   // wavefronts of this workgroup that sleep on an LDS ticket
       ++phase;
       want0 = base0 + (unsigned)(phase - 1) * cnt0 + ord0;
       want1 = base1 + (unsigned)(phase - 1) * cnt1 + ord1;
@@ -123,7 +125,12 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
       ok = false;
       alive = false;
     }
-    if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
+    if (!__any(ready)) {
+      // a lane that waits on a body shared with another workgroup has to keep looking at global
+      // memory; a wavefront whose lanes all wait on LDS tickets is woken by s_wakeup
+      if (__any(alive && (sh0 || sh1))) __builtin_amdgcn_s_sleep(1);
+      else __builtin_amdgcn_s_sleep(32);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();

@@ -231,3 +231,16 @@ def test_quad_schedule_with_256_constraint_tiles(ctx, method):
         x32, a32, st = gpu_solve(ctx, s, rhs, 0.02, method, 20, precision=capi.F32)
         xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.02, method, max_iters=20)
         assert same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR, capi.JACOBI])
+def test_islands_up_to_512_constraints_stay_in_one_workgroup(ctx, method):
+    """An island of 257..512 constraints runs in ONE 512-thread tile (all
+    hand-offs in LDS) instead of the cross-workgroup patch path."""
+    rng = np.random.default_rng(43)
+    s, rhs = random_system(rng, 70, 430, world_frac=0.1, connected=True)
+    for K in (1, 8, 40):
+        x, a, st = gpu_solve(ctx, s, rhs, 0.02, method, K)
+        assert st.status == capi.OK and st.n_global == 0 and st.n_tiles == 1
+        xf, af, _, rf = orc.fast_iterate(s, rhs, 0.02, method, max_iters=K, tol=0.0)
+        assert same_bits(x, xf) and same_bits(a, af), K
