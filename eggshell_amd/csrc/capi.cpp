@@ -68,6 +68,7 @@ constexpr size_t kEventPairs = 4096;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr int kQuadMaxConstraints = 32768;
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
+constexpr int kMaxQuadPatchTiles = 256;      // one 1024-thread workgroup per CU
 constexpr int kMaxPatchTiles = 512;          // 2 resident 256-thread workgroups per CU at 232 VGPRs  // above this the 1-lane tiles fill the GPU better
 
 struct HipError : std::runtime_error {
@@ -141,6 +142,7 @@ struct egs_problem {
   Plan planq;
   bool use_quad = false;
   bool patch_enabled = true;   // EGS_PATCH=0 forces the all-global path for oversize islands
+  bool quad_patch = false;     // patches run on the 4-lanes-per-constraint kernel (EGS_QUAD_PATCH=0: 1 lane)
   DevBuf<LaneDesc> q_lanes;
   DevBuf<int32_t> q_tile_nslots, q_tile_slot_off, q_slot_body;
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
@@ -291,7 +293,15 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.cfm = cfm; a.kscale = kscale; a.sweeps = sweeps; a.resume = resume;
     a.max_slots = p->plan.patch_max_slots; a.spin_limit = kSpinLimit;
     HIPCHK(hipMemsetAsync(p->gtickets.p, 0, sizeof(uint32_t) * (size_t)(p->n > 0 ? p->n : 1), ctx->stream));
-    launch_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
+    if (p->quad_patch && p->plan.n_patch_tiles <= kMaxQuadPatchTiles) {
+      // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
+      a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
+      a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
+      launch_cons_prepare<REAL>(a, ctx->stream);
+      launch_quad_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
+    } else {
+      launch_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
+    }
     GlobalArgs<REAL> g{};
     g.cons = p->gcons.p; g.mg = (int)p->plan.global.size();
     g.J0 = a.J0; g.J1 = a.J1; g.rhs = a.rhs; g.x = a.x; g.acc = a.acc; g.wres = a.wres; g.cfm = cfm;
@@ -595,6 +605,12 @@ void ensure_tile_plan(egs_problem *p) {
     stage(p->ctx, p->p_slot_body, pl.patch_slot_body);
     const char *pe = std::getenv("EGS_PATCH");
     p->patch_enabled = !(pe && std::atoi(pe) == 0);
+    const char *qp = std::getenv("EGS_QUAD_PATCH");
+    p->quad_patch = pl.block == 256 && pl.n_patch_tiles <= kMaxQuadPatchTiles && !(qp && std::atoi(qp) == 0);
+    if (p->quad_patch) {
+      const size_t rsz = p->real_size(), mm2 = (size_t)m;
+      p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
+    }
   }
   const size_t mg = pl.global.size(), rsz = p->real_size();
   p->gB0.alloc(mg * 18 * rsz); p->gB1.alloc(mg * 18 * rsz); p->gD.alloc(mg * 9 * rsz);

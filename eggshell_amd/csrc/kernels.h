@@ -80,6 +80,8 @@ void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s);
 template <typename REAL>
 void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s);
 template <typename REAL>
+void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s);
+template <typename REAL>
 void launch_assemble(const AssembleArgs &a, hipStream_t s);
 // partial sums of squares by row category: out[4*blocks]
 template <typename REAL>

@@ -55,6 +55,11 @@ __device__ __forceinline__ T quad_sum(T p) {  // (p0 + p1) + (p2 + p3) on every 
   return p;
 }
 
+template <typename T>
+__device__ __forceinline__ T gld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void gst(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ unsigned lds_load_acquire(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -115,8 +120,15 @@ __device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
 }
 
 // QT = constraints per tile; the workgroup has 4 * QT threads (64 -> 256, 256 -> 1024).
-template <typename REAL, int METHOD, int QT>
-__global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL> A) {
+// PATCH = true: the tile is a body patch of an island larger than a workgroup
+// (plan.cpp::build_patches).  A side whose slot is kSharedSlot belongs to a body
+// that other workgroups touch too: its accumulator and ticket live in global
+// memory (A.acc, g_tick) and are handed over with sc1 stores -> s_waitcnt
+// vmcnt(0) -> sc1 ticket store / sc1 ticket poll -> sc1 loads, as in
+// patch_solve_kernel.  w = A x - rhs is then left to a follow-up kernel (the
+// shared accumulators are final only when every patch has finished).
+template <typename REAL, int METHOD, int QT, bool PATCH>
+__global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL> A, uint32_t *g_tick) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
   unsigned *s_tick = reinterpret_cast<unsigned *>(smem + (size_t)A.max_slots * 6 * sizeof(REAL));
@@ -134,11 +146,20 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
 
   const LaneDesc d = A.lanes[(size_t)tile * QT + (tid >> 2)];
   const bool active = d.cidx >= 0;
-  const int slot = side ? d.slot1 : d.slot0;
-  const bool has = active && slot != 0;            // this lane's body is a real body
+  const int raw_slot = side ? d.slot1 : d.slot0;
+  const bool has = active && raw_slot != 0;        // this lane's body is a real body
+  const bool sh = PATCH && has && raw_slot == kSharedSlot;   // ... shared with other workgroups
+  const int slot = sh ? 0 : raw_slot;              // shared sides park on the zero slot
   const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
   REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
   unsigned *my_tick = s_tick + slot;
+  REAL *g_acc = A.acc;
+  uint32_t *g_t = g_tick;
+  if (sh) {
+    const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
+    g_acc = A.acc + (size_t)body * 6 + 3 * half;
+    g_t = g_tick + body;
+  }
 
   REAL Jh[9], Bh[9], Dl[3], inv[3], rhs[3], lo[3], hi[3], x[3];
   bool eq[3];
@@ -180,7 +201,25 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     bool pending = has;
     unsigned spins = 0;
     while (pending) {
-      if (lds_load_acquire(my_tick) == pos) {
+      if (sh) {
+        if (gld(g_t) == pos) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            REAL t = tfma(Bh[3 * k + 0], x[0], gld(g_acc + k));
+            t = tfma(Bh[3 * k + 1], x[1], t);
+            t = tfma(Bh[3 * k + 2], x[2], t);
+            gst(g_acc + k, t);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both halves' stores (one wavefront) have landed
+          if (half == 0) gst(g_t, pos + 1u);
+          pending = false;
+        } else if (++spins > A.spin_limit) {
+          ok = false;
+          pending = false;
+        }
+      } else if (lds_load_acquire(my_tick) == pos) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           REAL t = tfma(Bh[3 * k + 0], x[0], my_acc[k]);
@@ -208,11 +247,19 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     while (alive) {
       unsigned t;
       REAL a[3];
+      unsigned gt = want;
+      if (sh) gt = gld(g_t);
       poll3(tick_addr, acc_addr, t, a);
+      if (sh) t = gt;
       int rdy = (!has || t == want) ? 1 : 0;
       rdy &= dpp_i<kXor1>(rdy);
       rdy &= dpp_i<kXor2>(rdy);
       if (rdy) {
+        if (sh) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
+        }
         REAL res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -253,8 +300,16 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             u = tfma(Bh[3 * k + 1], dx[1], u);
             an[k] = tfma(Bh[3 * k + 2], dx[2], u);
           }
-          store3(acc_addr, an);
-          if (half == 0) store_tick(tick_addr, want + 1u);
+          if (sh) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (half == 0) gst(g_t, want + 1u);
+          } else {
+            store3(acc_addr, an);
+            if (half == 0) store_tick(tick_addr, want + 1u);
+          }
         }
         want += cnt;
         spins = 0;
@@ -270,7 +325,12 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
 
   if (!ok) atomicOr(A.error_flag, 1);
 
-  if (active) {  // lambda and w = A x - rhs with the final accumulators
+  if (PATCH) {
+    if (active && q == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) A.x[(size_t)d.cidx * 3 + r] = x[r];
+    }
+  } else if (active) {  // lambda and w = A x - rhs with the final accumulators
     REAL a[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) a[k] = my_acc[k];
@@ -299,18 +359,32 @@ template <typename REAL>
 void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s) {
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
+  uint32_t *none = nullptr;
   if (tile_size == 64) {
-    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 64>), dim3(n_tiles), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 64>), dim3(n_tiles), dim3(256), lds, s, a);
+    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 64, false>), dim3(n_tiles), dim3(256), lds, s, a, none);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 64, false>), dim3(n_tiles), dim3(256), lds, s, a, none);
   } else if (tile_size == 256) {
-    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256>), dim3(n_tiles), dim3(1024), lds, s, a);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256>), dim3(n_tiles), dim3(1024), lds, s, a);
+    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, false>), dim3(n_tiles), dim3(1024), lds, s, a, none);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, false>), dim3(n_tiles), dim3(1024), lds, s, a, none);
   } else {
     throw std::invalid_argument("launch_quad_solve: tile size must be 64 or 256");
   }
 }
 
+// Body patches of oversize islands, 256 constraints = 1024 threads per patch
+// (one workgroup per CU at 96 VGPRs: the host keeps n_tiles <= 256 so that all
+// patches are co-resident).
+template <typename REAL>
+void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s) {
+  if (n_tiles <= 0) return;
+  const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
+  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+}
+
 template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
 template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, int, hipStream_t);
+template void launch_quad_patch_solve<double>(const SolveArgs<double> &, int, int, uint32_t *, hipStream_t);
+template void launch_quad_patch_solve<float>(const SolveArgs<float> &, int, int, uint32_t *, hipStream_t);
 
 }  // namespace egs

@@ -1,5 +1,6 @@
 """GPU (-m gpu): oversize islands as body patches (LDS for private bodies, global
-hand-off for shared ones) vs the all-global path (EGS_PATCH=0) vs the oracle:
+hand-off for shared ones; 4 lanes or 1 lane per constraint) vs the all-global path
+(EGS_PATCH=0) vs the oracle:
 identical bits; tol-terminated runs (resume launches) included."""
 import numpy as np
 import pytest
@@ -33,15 +34,36 @@ def test_patch_and_global_paths_agree(ctx, method, monkeypatch):
         rhs = rng.uniform(-1, 1, 3 * s.m)
         for K in (0, 1, 7, 30):
             xf, af, _, rf = orc.fast_iterate(s, rhs, 0.05, method, max_iters=K, tol=0.0)
-            for patch in ("1", "0"):
+            # patches on the 4-lanes-per-constraint kernel (default), on the 1-lane kernel, all-global
+            for patch, quad_patch in (("1", "1"), ("1", "0"), ("0", "1")):
                 monkeypatch.setenv("EGS_PATCH", patch)
+                monkeypatch.setenv("EGS_QUAD_PATCH", quad_patch)
                 x, a, st = solve(ctx, s, rhs, 0.05, method, K)
                 assert st.status == capi.OK and st.n_global > 256
-                assert np.array_equal(x, xf) and np.array_equal(a, af), (patch, K)
+                assert np.array_equal(x, xf) and np.array_equal(a, af), (patch, quad_patch, K)
                 assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
     monkeypatch.setenv("EGS_PATCH", "1")
+    monkeypatch.setenv("EGS_QUAD_PATCH", "1")
     s = cases[1]
     rhs = rng.uniform(-1, 1, 3 * s.m)
     x, a, st = solve(ctx, s, rhs, 0.5, method, 500, tol=1e-9)
     xf, af, it, rf = orc.fast_iterate(s, rhs, 0.5, method, max_iters=500, tol=1e-9)
     assert st.iterations == it and np.array_equal(x, xf)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_patches_in_fp32(ctx, method, monkeypatch):
+    """The fp32 mode (C4 precision) on an oversize island: both patch kernels give
+    the fp32 oracle's bits."""
+    rng = np.random.default_rng(61)
+    s, rhs = random_system(rng, 200, 1500, connected=True)
+    xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, 0.05, method, max_iters=25)
+    for quad_patch in ("1", "0"):
+        monkeypatch.setenv("EGS_QUAD_PATCH", quad_patch)
+        pr = capi.Problem(ctx, s.n, s.body0, s.body1, precision=capi.F32)
+        pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+        st = pr.solve(capi.params(method=method, max_iters=25, tol=0.0, cfm=0.05))
+        x, a = pr.lambda_(), pr.accumulators()
+        pr.close()
+        assert st.status == capi.OK and st.n_global > 256
+        assert np.array_equal(x.astype(np.float32), xo) and np.array_equal(a.astype(np.float32), ao), quad_patch
