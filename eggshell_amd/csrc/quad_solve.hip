@@ -18,22 +18,15 @@
 #include <stdexcept>
 
 #include "kernels.h"
+#include "solve_device.h"
+
+#ifndef EGS_QUAD_SLEEP
+#define EGS_QUAD_SLEEP 32
+#endif
 
 namespace egs {
 
 namespace {
-
-template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
-template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
-template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-template <typename T>
-__device__ __forceinline__ T project(T x, bool eq, T lo, T hi) {  // sparse_iterations_utils.cc:12-21
-  T r = x;
-  r = (x > hi) ? hi : r;
-  r = (x < lo) ? lo : r;
-  return eq ? x : r;
-}
 
 // quad_perm DPP: value of lane (l ^ 1) / (l ^ 2) inside each group of 4 lanes
 template <int CTRL>
@@ -55,18 +48,6 @@ __device__ __forceinline__ T quad_sum(T p) {  // (p0 + p1) + (p2 + p3) on every 
   return p;
 }
 
-template <typename T>
-__device__ __forceinline__ T gld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T>
-__device__ __forceinline__ void gst(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ unsigned lds_load_acquire(const unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(unsigned *p, unsigned v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // ---- ordered LDS hand-off, hand-placed ---------------------------------------
 // A wavefront's DS instructions execute in issue order.  Consumer: ticket load,
 // then the 3 accumulator loads, ONE wait for all four -- if the ticket matches,
@@ -74,9 +55,6 @@ __device__ __forceinline__ void lds_store_release(unsigned *p, unsigned v) {
 // before we bump its ticket).  Producer: accumulator stores, then the ticket
 // store; no wait in between.  (volatile C++ accesses were tried first: hipcc
 // lowers them to flat sc0 sc1 loads with a vmcnt(0) after each.)
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
-}
 __device__ __forceinline__ void poll3(unsigned tick_addr, unsigned acc_addr, unsigned &t, double (&a)[3]) {
   asm volatile(
       "ds_read_b32 %0, %4\n\t"
@@ -114,9 +92,6 @@ __device__ __forceinline__ void store3(unsigned acc_addr, const float (&a)[3]) {
       "ds_write_b32 %0, %3 offset:8"
       :: "v"(acc_addr), "v"(a[0]), "v"(a[1]), "v"(a[2])
       : "memory");
-}
-__device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
-  asm volatile("ds_write_b32 %0, %1" :: "v"(tick_addr), "v"(v) : "memory");
 }
 
 // QT = constraints per tile; the workgroup has 4 * QT threads (64 -> 256, 256 -> 1024).
@@ -311,6 +286,10 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             if (half == 0) store_tick(tick_addr, want + 1u);
           }
         }
+        // 1024-thread tiles: 16 wavefronts share one LDS; the idle ones sleep (see kernels.hip).
+        // Measured: +6 % on a moving C3 pile; slower on body patches (waits on global tickets
+        // cannot be woken), so not there.
+        if (QT >= 256 && !PATCH) asm volatile("s_wakeup");
         want += cnt;
         spins = 0;
         alive = ++sweep <= A.sweeps;
@@ -318,6 +297,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         ok = false;
         alive = false;
       }
+      if (QT >= 256 && !PATCH && !__any(rdy)) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
