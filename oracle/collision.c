@@ -5,6 +5,7 @@
  * col(R,j) is the j-th column (a box axis in world coordinates). */
 #include <float.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "egs_oracle.h"
 #include "linalg.h"
@@ -113,11 +114,38 @@ static int box_rect(const box_t *B, const box_t *Rc, v2 *poly) {
   return n;
 }
 
+/* test hooks: the helpers above, so that tests/test_oracle_collision.py can restate
+ * the reference's own tests of them (collision.cc:527-681) */
+void orc_line_closest_approach(const double pa[3], const double ua[3], const double pb[3],
+                               const double ub[3], double *alpha, double *beta) {
+  line_closest_approach(pa, ua, pb, ub, alpha, beta);
+}
+int orc_clip_polygon(const double *poly_xy, int n, const double normal[2], double d, double *out_xy) {
+  v2 in[32], out[64];
+  if (n > 32) return -1;
+  for (int i = 0; i < n; ++i) in[i] = (v2){poly_xy[2 * i], poly_xy[2 * i + 1]};
+  int k = clip_poly(in, n, (v2){normal[0], normal[1]}, d, out);
+  for (int i = 0; i < k; ++i) { out_xy[2 * i] = out[i].x; out_xy[2 * i + 1] = out[i].y; }
+  return k;
+}
+/* box B vs rectangle (centre, R, half[0..1]); polygon [<=32][2] in the rectangle's frame */
+int orc_box_rectangle(const double bc[3], const double bR[9], const double bhalf[3], const double rc[3],
+                      const double rR[9], const double rhalf[2], double *poly_xy) {
+  box_t B, Rc;
+  for (int k = 0; k < 3; ++k) { B.center[k] = bc[k]; B.half[k] = bhalf[k]; Rc.center[k] = rc[k]; }
+  memcpy(B.R, bR, sizeof B.R); memcpy(Rc.R, rR, sizeof Rc.R);
+  Rc.half[0] = rhalf[0]; Rc.half[1] = rhalf[1]; Rc.half[2] = 0;
+  v2 poly[32];
+  int n = box_rect(&B, &Rc, poly);
+  for (int i = 0; i < n; ++i) { poly_xy[2 * i] = poly[i].x; poly_xy[2 * i + 1] = poly[i].y; }
+  return n;
+}
+
 /* collision.cc:166-388 */
-int orc_collide_boxes(const double c1[3], const double R1[9],
-                      const double s1[3], const double c2[3],
-                      const double R2[9], const double s2[3], double *contacts,
-                      int max_contacts, int *code_out) {
+static int collide_boxes_impl(const double c1[3], const double R1[9],
+                              const double s1[3], const double c2[3],
+                              const double R2[9], const double s2[3], double *contacts,
+                              int max_contacts, int *code_out, double *info /* axis[3], depth; or NULL */) {
   const double kAlign = 0.9962, kTol = 1e-9;
   box_t box1, box2;
   for (int k = 0; k < 3; ++k) {
@@ -208,6 +236,11 @@ int orc_collide_boxes(const double c1[3], const double R1[9],
     sep_EE[0] = t[0]; sep_EE[1] = t[1]; sep_EE[2] = t[2];
   }
   int best_FN = (code_EE == 0) ? 1 : (min_FN > min_EE);
+  if (info) { /* CollisionInfo, collision.cc:283-291 */
+    const double *ax = best_FN ? sep_FN : sep_EE;
+    info[0] = ax[0]; info[1] = ax[1]; info[2] = ax[2];
+    info[3] = best_FN ? -min_FN : -min_EE;
+  }
   int n = 0;
   if (aacount == 0 && !best_FN) { /* edge-edge, :278-301 */
     if (code_out) *code_out = code_EE;
@@ -286,4 +319,19 @@ int orc_collide_boxes(const double c1[3], const double R1[9],
     n = 1;
   }
   return n;
+}
+
+int orc_collide_boxes(const double c1[3], const double R1[9],
+                      const double s1[3], const double c2[3],
+                      const double R2[9], const double s2[3], double *contacts,
+                      int max_contacts, int *code_out) {
+  return collide_boxes_impl(c1, R1, s1, c2, R2, s2, contacts, max_contacts, code_out, 0);
+}
+
+/* the same, also returning CollisionInfo {separating_axis, depth} (collision.h:29-38) */
+int orc_collide_boxes_info(const double c1[3], const double R1[9],
+                           const double s1[3], const double c2[3],
+                           const double R2[9], const double s2[3], double *contacts,
+                           int max_contacts, int *code_out, double info[4]) {
+  return collide_boxes_impl(c1, R1, s1, c2, R2, s2, contacts, max_contacts, code_out, info);
 }

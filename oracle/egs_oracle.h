@@ -156,6 +156,18 @@ int orc_collide_boxes(const double c1[3], const double R1[9],
                       const double R2[9], const double s2[3], double *contacts,
                       int max_contacts, int *code_out);
 
+/* the same with CollisionInfo {separating_axis[3], depth} (collision.h) */
+int orc_collide_boxes_info(const double c1[3], const double R1[9],
+                           const double s1[3], const double c2[3],
+                           const double R2[9], const double s2[3], double *contacts,
+                           int max_contacts, int *code_out, double info[4]);
+/* test hooks for collision.cc:53-164 */
+void orc_line_closest_approach(const double pa[3], const double ua[3], const double pb[3],
+                               const double ub[3], double *alpha, double *beta);
+int orc_clip_polygon(const double *poly_xy, int n, const double normal[2], double d, double *out_xy);
+int orc_box_rectangle(const double bc[3], const double bR[9], const double bhalf[3], const double rc[3],
+                      const double rR[9], const double rhalf[2], double *poly_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,6 +270,35 @@ def collide_box_ground(c, R, side=(0.3, 0.3, 0.3)):
     return out[:n].copy()
 
 
+def line_closest_approach(pa, ua, pb, ub):
+    a, b = C.c_double(0), C.c_double(0)
+    lib().orc_line_closest_approach(_p(_f64(pa)), _p(_f64(ua)), _p(_f64(pb)), _p(_f64(ub)), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def clip_polygon(poly, normal, d):
+    poly = _f64(poly)
+    out = np.zeros((64, 2))
+    k = lib().orc_clip_polygon(_p(poly), C.c_int(poly.shape[0]), _p(_f64(normal)), C.c_double(d), _p(out))
+    return out[:k].copy()
+
+
+def box_rectangle(bc, bR, bhalf, rc, rR, rhalf):
+    out = np.zeros((32, 2))
+    k = lib().orc_box_rectangle(_p(_f64(bc)), _p(_f64(bR)), _p(_f64(bhalf)), _p(_f64(rc)), _p(_f64(rR)),
+                                _p(_f64(rhalf)), _p(out))
+    return out[:k].copy()
+
+
+def collide_boxes_info(c1, R1, c2, R2, s1=(0.3, 0.3, 0.3), s2=(0.3, 0.3, 0.3)):
+    """CollideBoxes with its CollisionInfo: (contacts[n][7], code, separating_axis[3], depth)."""
+    c1, R1, c2, R2, s1, s2 = _f64(c1), _f64(R1), _f64(c2), _f64(R2), _f64(s1), _f64(s2)
+    out = np.zeros((16, 7)); code = C.c_int(0); info = np.zeros(4)
+    n = lib().orc_collide_boxes_info(_p(c1), _p(R1), _p(s1), _p(c2), _p(R2), _p(s2), _p(out),
+                                     C.c_int(16), C.byref(code), _p(info))
+    return out[:n].copy(), code.value, info[:3].copy(), float(info[3])
+
+
 def collide_boxes(c1, R1, c2, R2, s1=(0.3, 0.3, 0.3), s2=(0.3, 0.3, 0.3)):
     c1, R1, c2, R2, s1, s2 = _f64(c1), _f64(R1), _f64(c2), _f64(R2), _f64(s1), _f64(s2)
     out = np.zeros((16, 7)); code = C.c_int(0)
