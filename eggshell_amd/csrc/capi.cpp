@@ -54,6 +54,7 @@ struct PinnedArena {
 struct egs_context {
   PinnedArena pinned;
   int device = 0;
+  int cu_count = 256;   // co-residency caps of the cross-workgroup kernels scale with it
   hipStream_t stream = nullptr;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::string error;
@@ -68,8 +69,11 @@ constexpr size_t kEventPairs = 4096;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr int kQuadMaxConstraints = 32768;
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
-constexpr int kMaxQuadPatchTiles = 256;      // one 1024-thread workgroup per CU
-constexpr int kMaxPatchTiles = 512;          // 2 resident 256-thread workgroups per CU at 232 VGPRs  // above this the 1-lane tiles fill the GPU better
+// Patches wait on each other, so all of a launch's patches must be co-resident:
+// one 1024-thread workgroup (4 lanes per constraint) or two 256-thread workgroups
+// (232 VGPRs) per CU.
+inline int max_quad_patch_tiles(const egs_context *ctx) { return ctx->cu_count; }
+inline int max_patch_tiles(const egs_context *ctx) { return 2 * ctx->cu_count; }
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -239,7 +243,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
   const bool quad = p->use_quad && method != EGS_JACOBI;
   if (!quad) ensure_tile_plan(p);
   const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 &&
-                     p->plan.n_patch_tiles <= kMaxPatchTiles && p->patch_enabled;
+                     p->plan.n_patch_tiles <= max_patch_tiles(ctx) && p->patch_enabled;
   record_kernel_event(ctx, true);
   if (patch && !resume)  // shared bodies accumulate in global memory from zero
     HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * sizeof(REAL), ctx->stream));
@@ -293,7 +297,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.cfm = cfm; a.kscale = kscale; a.sweeps = sweeps; a.resume = resume;
     a.max_slots = p->plan.patch_max_slots; a.spin_limit = kSpinLimit;
     HIPCHK(hipMemsetAsync(p->gtickets.p, 0, sizeof(uint32_t) * (size_t)(p->n > 0 ? p->n : 1), ctx->stream));
-    if (p->quad_patch && p->plan.n_patch_tiles <= kMaxQuadPatchTiles) {
+    if (p->quad_patch && p->plan.n_patch_tiles <= max_quad_patch_tiles(ctx)) {
       // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
       a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
@@ -501,6 +505,9 @@ egs_status egs_context_create(int device_index, egs_context **out) {
   ctx->device = device_index;
   egs_status st = guarded(ctx, [&]() -> egs_status {
     HIPCHK(hipSetDevice(device_index));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_index));
+    if (prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ctx->t0));
     HIPCHK(hipEventCreate(&ctx->t1));
@@ -606,7 +613,7 @@ void ensure_tile_plan(egs_problem *p) {
     const char *pe = std::getenv("EGS_PATCH");
     p->patch_enabled = !(pe && std::atoi(pe) == 0);
     const char *qp = std::getenv("EGS_QUAD_PATCH");
-    p->quad_patch = pl.block == 256 && pl.n_patch_tiles <= kMaxQuadPatchTiles && !(qp && std::atoi(qp) == 0);
+    p->quad_patch = pl.block == 256 && pl.n_patch_tiles <= max_quad_patch_tiles(p->ctx) && !(qp && std::atoi(qp) == 0);
     if (p->quad_patch) {
       const size_t rsz = p->real_size(), mm2 = (size_t)m;
       p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
