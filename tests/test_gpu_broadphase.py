@@ -64,3 +64,27 @@ def test_grid_is_the_default_for_large_ensembles(ctx, monkeypatch):
     monkeypatch.setenv("EGS_BROADPHASE", "pairs")
     h0, h1, hd = ctx.update_contacts(sc["p"], sc["R"])
     assert np.array_equal(g0, h0) and np.array_equal(g1, h1) and np.array_equal(gd, hd)
+
+
+@pytest.mark.parametrize("mode", ["pairs", "grid"])
+def test_edge_cases_fail_loudly_or_return_empty(ctx, monkeypatch, mode):
+    """More than 64 overlapping partners for one body is a documented limit
+    (EGS_ERR_INVALID, no hang, no truncated list); too small an output buffer
+    likewise; one body far above the ground gives an empty list."""
+    from eggshell_amd import capi
+    monkeypatch.setenv("EGS_BROADPHASE", mode)
+    eye = np.eye(3).reshape(1, 9)
+    p = np.tile([[0.0, 0.0, 5.0]], (70, 1)) + np.arange(70)[:, None] * 1e-4      # 70 boxes in one spot
+    with pytest.raises(capi.EgsError) as e:
+        ctx.update_contacts(p, np.tile(eye, (70, 1)))
+    assert e.value.status == capi.ERR_INVALID
+    sc = scenes.box_stack(2, 2, 3)
+    with pytest.raises(capi.EgsError) as e:
+        ctx.update_contacts(sc["p"], sc["R"], max_contacts=10)
+    assert e.value.status == capi.ERR_INVALID
+    g0, g1, gd = ctx.update_contacts(np.array([[0.0, 0.0, 3.0]]), eye)
+    assert len(g0) == 0 and gd.shape == (0, 7)
+    g0, g1, gd = ctx.update_contacts(np.array([[0.0, 0.0, 0.149]]), eye)          # one box resting on the ground
+    assert len(g0) == 4 and (g0 == -1).all() and (g1 == 0).all()
+    g0, g1, gd = ctx.update_contacts(sc["p"], sc["R"])                            # the context still works
+    assert len(g0) == 48
