@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="independent piles resident per GPU")
+    ap.add_argument("--batch", type=int, default=24, help="independent piles resident per GPU (24 x 1024 columns = two full rounds of 3 tiles per CU)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")

@@ -73,6 +73,19 @@ constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 
 // one 1024-thread workgroup (4 lanes per constraint) or two 256-thread workgroups
 // (232 VGPRs) per CU.
 inline int max_quad_patch_tiles(const egs_context *ctx) { return ctx->cu_count; }
+
+// Isotropic bodies, fp64, batched work: the register-light tile kernel (no stored B, three
+// 256-constraint tiles per CU) against the regular one (512-constraint tiles, one per CU).
+// Tiles are dispatched in rounds of 3C resp. C, so the better choice depends on how the
+// tile count quantises; per-round times (ms, C3 columns, 100 sweeps) measured on MI355X.
+inline bool iso_schedule_pays(long m, int cu) {
+  const long t = (m + 255) / 256;                       // 256-constraint tiles
+  if (t < 2L * cu) return false;                       // fewer than two tiles per CU: registers are not the limit
+  const long full3 = t / (3L * cu), rem3 = t % (3L * cu);
+  const double iso = 0.66 * full3 + (rem3 == 0 ? 0.0 : rem3 <= cu ? 0.45 : rem3 <= 2L * cu ? 0.57 : 0.66);
+  const double regular = 0.53 * ((t / 2 + cu - 1) / cu);
+  return iso < regular;
+}
 inline int max_patch_tiles(const egs_context *ctx) { return 2 * ctx->cu_count; }
 
 struct HipError : std::runtime_error {
@@ -164,6 +177,7 @@ struct egs_problem {
   DevBuf<uint8_t> is_eq;
   DevBuf<int32_t> error_flag;
   bool have_blocks = false, have_state = false, have_constraints = false, minv_r_valid = false;
+  bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
   size_t real_size() const { return precision == EGS_F32 ? sizeof(float) : sizeof(double); }
 };
@@ -226,6 +240,21 @@ void ensure_minv_real(egs_problem *p) {
   else
     launch_convert_minv<double>(count, p->Minv_d.p, reinterpret_cast<double *>(p->Minv_r.p), p->ctx->stream);
   p->minv_r_valid = true;
+  // isotropy of the blocks, checked once per upload (4 bytes back)
+  const char *ie = std::getenv("EGS_ISO");
+  if (p->n > 0 && !(ie && std::atoi(ie) == 0)) {
+    hipStream_t s = p->ctx->stream;
+    int one = 1, flag = 0;
+    HIPCHK(hipMemcpyAsync(p->error_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    if (p->precision == EGS_F32) launch_minv_iso<float>(p->n, reinterpret_cast<const float *>(p->Minv_r.p), p->error_flag.p, s);
+    else launch_minv_iso<double>(p->n, reinterpret_cast<const double *>(p->Minv_r.p), p->error_flag.p, s);
+    HIPCHK(hipMemcpyAsync(&flag, p->error_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int), s));
+    HIPCHK(hipStreamSynchronize(s));
+    const bool iso = flag != 0;
+    if (iso != p->minv_iso) p->tile_plan_ready = false;   // the preferred tile size depends on it
+    p->minv_iso = iso;
+  }
 }
 
 void record_kernel_event(egs_context *ctx, bool begin) {
@@ -273,6 +302,8 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.resume = resume;
     a.max_slots = quad ? p->planq.max_slots : p->plan.max_slots;
     a.spin_limit = kSpinLimit;
+    a.iso = (p->minv_iso && p->precision == EGS_F64 && !quad && p->plan.block == 256 &&
+             iso_schedule_pays(p->m, ctx->cu_count)) ? 1 : 0;
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
       launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
@@ -391,6 +422,7 @@ egs_status validate_params(egs_context *ctx, const egs_solve_params *prm) {
 }
 
 void fill_stats(egs_problem *p, egs_solve_stats *st) {
+  if (!p->use_quad) ensure_tile_plan(p);
   const Plan &pl = p->use_quad ? p->planq : p->plan;   // islands and ticket periods agree between the two
   st->n_islands = pl.n_islands;
   st->n_tiles = pl.n_tiles;
@@ -408,6 +440,8 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     if (stats) { std::memset(stats, 0, sizeof *stats); fill_stats(p, stats); }
     return EGS_OK;
   }
+  ensure_minv_real(p);   // also decides the isotropic fast path, hence the tile size
+  if (!p->use_quad || prm->method == EGS_JACOBI) ensure_tile_plan(p);
   HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream));
   if (!(prm->tol > 0)) {
     // tickets are 32-bit counters that advance by cnt per sweep: very long runs
@@ -584,11 +618,12 @@ void ensure_tile_plan(egs_problem *p) {
   const int n = p->n, m = p->m;
   {
     // 256 constraints per tile; 512 once there are enough tiles to give every CU two
-    // anyway (all 64 lanes of the working wavefront busy: +3-4 % on 16 batched C3 piles).
+    // anyway (all 64 lanes of the working wavefront busy: +3-4 % on 16 batched C3 piles) --
+    // but not for isotropic bodies, whose register-light kernel fits THREE 256-thread tiles per CU.
     // Oversize islands (patch / global kernels) always use 256 -- unless 512 makes every island fit.
     const char *te = std::getenv("EGS_TILE");   // experiment knob: 64/128/256/512 constraints per tile
     const int forced = te ? std::atoi(te) : 0;
-    int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints ? 512 : 256);
+    int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints && !(p->minv_iso && p->precision == EGS_F64 && iso_schedule_pays(m, p->ctx->cu_count)) ? 512 : 256);
     p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), tile);
     if (!forced && !p->plan.global.empty()) {
       if (tile == 256) {   // islands of 257..512 constraints: one 512-thread workgroup, all hand-offs in LDS
@@ -677,7 +712,8 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
   HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
   HIPCHK(hipStreamSynchronize(s));
-  if (!p->use_quad) ensure_tile_plan(p);
+  // the 1-lane schedule is built at the first solve that needs it (ensure_tile_plan):
+  // its tile size depends on the mass blocks, which arrive after the topology
 }
 
 egs_status check_topology(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0, const int32_t *body1) {

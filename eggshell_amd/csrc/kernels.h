@@ -31,6 +31,7 @@ struct SolveArgs {
   REAL cfm, kscale;
   int32_t sweeps, resume, max_slots;
   uint32_t spin_limit;
+  int iso = 0;              // 1: every M^-1 block is diag(a,a,a,b,b,b): B is formed on the fly (tile kernel)
 };
 
 template <typename REAL>
@@ -95,6 +96,9 @@ void launch_velocity(int n, const double *v, const double *w,
                      double dt, double *v6, hipStream_t s);
 template <typename REAL>
 void launch_convert_minv(int count, const double *src, REAL *dst, hipStream_t s);
+// *flag (preset to 1) is cleared unless every 6x6 block is exactly diag(a, a, a, b, b, b)
+template <typename REAL>
+void launch_minv_iso(int n, const REAL *W, int *flag, hipStream_t s);
 
 void launch_advance(int n, double *pos, double *R, double *v, double *w, const double *v6, double dt,
                     hipStream_t s);

@@ -61,6 +61,23 @@ __device__ __forceinline__ void acc_add(T *a, const T *B, const T *d) {
   }
 }
 
+// The same with B[c][r] = w_c J[r][c] formed on the fly (isotropic bodies: W is
+// diagonal with equal linear and equal angular entries).  One rounding per
+// product, as in the stored B, so the bits are those of acc_add.
+template <typename T>
+__device__ __forceinline__ void acc_add_iso(T *a, const T *J, T wl, T wa, const T *d) {
+  // Opaque to the optimiser: otherwise the loop-invariant products w * J are hoisted out of
+  // the sweep loop, i.e. B is back in 72 registers (or in scratch).
+  asm volatile("" : "+v"(wl), "+v"(wa));
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const T w = c < 3 ? wl : wa;
+    T t = tfma(w * J[c], d[0], a[c]);
+    t = tfma(w * J[6 + c], d[1], t);
+    t = tfma(w * J[12 + c], d[2], t);
+    a[c] = t;
+  }
+}
 __device__ __forceinline__ unsigned lds_load_acquire(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -74,12 +91,22 @@ struct Cons {
   REAL J0[18], J1[18];  // 3x6 row-major, zero for a world side
   REAL B0[18], B1[18];  // (W J^T) as 6x3 row-major
   REAL D[9];            // J0 B0 + J1 B1
+  REAL wl0, wa0, wl1, wa1;  // ISO mode: W = diag(wl, wl, wl, wa, wa, wa) per body, B is not stored
   REAL inv[3];          // 1 / ((D_rr + cfm) * kscale)
   REAL rhs[3], lo[3], hi[3];
   bool eq[3];
 };
 
-template <typename REAL>
+template <bool ISO, typename REAL>
+__device__ __forceinline__ void acc_add_side0(REAL *a, const Cons<REAL> &c, const REAL *d) {
+  if (ISO) acc_add_iso(a, c.J0, c.wl0, c.wa0, d); else acc_add(a, c.B0, d);
+}
+template <bool ISO, typename REAL>
+__device__ __forceinline__ void acc_add_side1(REAL *a, const Cons<REAL> &c, const REAL *d) {
+  if (ISO) acc_add_iso(a, c.J1, c.wl1, c.wa1, d); else acc_add(a, c.B1, d);
+}
+
+template <typename REAL, bool ISO = false>
 __device__ __forceinline__ void load_cons(const SolveArgs<REAL> &A, int cidx, bool has0, bool has1,
                                           int body0, int body1, Cons<REAL> &c) {
 #pragma unroll
@@ -87,42 +114,61 @@ __device__ __forceinline__ void load_cons(const SolveArgs<REAL> &A, int cidx, bo
     c.J0[k] = has0 ? A.J0[(size_t)cidx * 18 + k] : REAL(0);
     c.J1[k] = has1 ? A.J1[(size_t)cidx * 18 + k] : REAL(0);
   }
+  c.wl0 = c.wa0 = c.wl1 = c.wa1 = REAL(0);
+  if (ISO) {
+    // B[k][q] = w_k J[q][k] is formed where it is needed; D = J0 B0 + J1 B1 in the stored-B order
+    if (has0) { c.wl0 = A.Minv[(size_t)body0 * 36]; c.wa0 = A.Minv[(size_t)body0 * 36 + 21]; }
+    if (has1) { c.wl1 = A.Minv[(size_t)body1 * 36]; c.wa1 = A.Minv[(size_t)body1 * 36 + 21]; }
 #pragma unroll
-  for (int k = 0; k < 18; ++k) { c.B0[k] = REAL(0); c.B1[k] = REAL(0); }
-  if (has0) {
-    const REAL *W = A.Minv + (size_t)body0 * 36;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int cc = 0; cc < 6; ++cc) {
-      REAL Wr[6];
+      for (int q = 0; q < 3; ++q) {
+        REAL d0 = c.J0[6 * r] * (c.wl0 * c.J0[6 * q]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
+        for (int k = 1; k < 6; ++k) d0 = tfma(c.J0[6 * r + k], (k < 3 ? c.wl0 : c.wa0) * c.J0[6 * q + k], d0);
+        REAL d1 = c.J1[6 * r] * (c.wl1 * c.J1[6 * q]);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) c.B0[3 * cc + r] = dot6(Wr, c.J0 + 6 * r);
+        for (int k = 1; k < 6; ++k) d1 = tfma(c.J1[6 * r + k], (k < 3 ? c.wl1 : c.wa1) * c.J1[6 * q + k], d1);
+        c.D[3 * r + q] = d0 + d1;
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { c.B0[k] = REAL(0); c.B1[k] = REAL(0); }
+    if (has0) {
+      const REAL *W = A.Minv + (size_t)body0 * 36;
+  #pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        REAL Wr[6];
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
+  #pragma unroll
+        for (int r = 0; r < 3; ++r) c.B0[3 * cc + r] = dot6(Wr, c.J0 + 6 * r);
+      }
     }
-  }
-  if (has1) {
-    const REAL *W = A.Minv + (size_t)body1 * 36;
-#pragma unroll
-    for (int cc = 0; cc < 6; ++cc) {
-      REAL Wr[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) c.B1[3 * cc + r] = dot6(Wr, c.J1 + 6 * r);
+    if (has1) {
+      const REAL *W = A.Minv + (size_t)body1 * 36;
+  #pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        REAL Wr[6];
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) Wr[k] = W[6 * cc + k];
+  #pragma unroll
+        for (int r = 0; r < 3; ++r) c.B1[3 * cc + r] = dot6(Wr, c.J1 + 6 * r);
+      }
     }
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      REAL d0 = c.J0[6 * r] * c.B0[q];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) d0 = tfma(c.J0[6 * r + k], c.B0[3 * k + q], d0);
-      REAL d1 = c.J1[6 * r] * c.B1[q];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) d1 = tfma(c.J1[6 * r + k], c.B1[3 * k + q], d1);
-      c.D[3 * r + q] = d0 + d1;
-    }
+  #pragma unroll
+    for (int r = 0; r < 3; ++r)
+  #pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        REAL d0 = c.J0[6 * r] * c.B0[q];
+  #pragma unroll
+        for (int k = 1; k < 6; ++k) d0 = tfma(c.J0[6 * r + k], c.B0[3 * k + q], d0);
+        REAL d1 = c.J1[6 * r] * c.B1[q];
+  #pragma unroll
+        for (int k = 1; k < 6; ++k) d1 = tfma(c.J1[6 * r + k], c.B1[3 * k + q], d1);
+        c.D[3 * r + q] = d0 + d1;
+      }
+}
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     c.inv[r] = REAL(1) / ((c.D[4 * r] + A.cfm) * A.kscale);

@@ -244,3 +244,32 @@ def test_islands_up_to_512_constraints_stay_in_one_workgroup(ctx, method):
         assert st.status == capi.OK and st.n_global == 0 and st.n_tiles == 1
         xf, af, _, rf = orc.fast_iterate(s, rhs, 0.02, method, max_iters=K, tol=0.0)
         assert same_bits(x, xf) and same_bits(a, af), K
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR, capi.JACOBI])
+def test_isotropic_fast_path_has_the_same_bits(ctx, method, monkeypatch):
+    """Bodies whose M^-1 blocks are exactly diag(a,a,a,b,b,b) (every BASELINE pile) take
+    the tile kernel that forms B = M^-1 J^T on the fly; EGS_ISO=0 keeps B in registers;
+    one stray 1e-18 off the diagonal falls back by itself.  All three: the oracle's bits."""
+    monkeypatch.setenv("EGS_QUAD", "0")
+    rng = np.random.default_rng(44)
+    s = system_from_scene(scenes.box_stack(6, 5, 4, jitter=1e-3, seed=3))[0]
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    for prec in (capi.F64, capi.F32):
+        if prec == capi.F32:
+            xf, af = orc.fast_iterate_f32(s, rhs, 0.02, method, max_iters=30)[:2]
+        else:
+            xf, af = orc.fast_iterate(s, rhs, 0.02, method, max_iters=30, tol=0.0)[:2]
+        for iso in ("1", "0"):
+            monkeypatch.setenv("EGS_ISO", iso)
+            x, a, st = gpu_solve(ctx, s, rhs, 0.02, method, 30, precision=prec)
+            if prec == capi.F32:
+                x, a = x.astype(np.float32), a.astype(np.float32)
+            assert st.status == capi.OK and same_bits(x, xf) and same_bits(a, af), (prec, iso)
+    monkeypatch.setenv("EGS_ISO", "1")
+    Minv = s.Minv.copy()
+    Minv[7, 1] = Minv[7, 6] = 1e-18                      # body 7 is no longer exactly isotropic
+    s2 = orc.Sys(Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi)
+    x, a, st = gpu_solve(ctx, s2, rhs, 0.02, method, 30)
+    xf, af, _, _ = orc.fast_iterate(s2, rhs, 0.02, method, max_iters=30, tol=0.0)
+    assert same_bits(x, xf) and same_bits(a, af)
