@@ -144,7 +144,7 @@ def run_workload(ctx, workload, batch, method, steps, warmup, rank, torch, tdist
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": (traffic[0] * m) if traffic else None,
         "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                           "measured on the 16-pile tile_solve_kernel run)" % (traffic[1], traffic[0])) if traffic else None,
+                           "measured on the tile_solve_kernel of this bench command)" % (traffic[1], traffic[0])) if traffic else None,
         "kernel": "quad_solve_kernel (+cons_prepare)" if st.reserved == 1 else "tile_solve_kernel",
         "kernel_ms": kernel_ms, "launches": klaunches, "algorithmic_bytes_per_launch": alg_bytes,
         "note": "algorithmic bytes = contacts x sweeps x %d B (SURVEY 8d); J blocks and body accumulators stay in "
