@@ -74,12 +74,14 @@ constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 
 // (232 VGPRs) per CU.
 inline int max_quad_patch_tiles(const egs_context *ctx) { return ctx->cu_count; }
 
-// Isotropic bodies, fp64, batched work: the register-light tile kernel (no stored B, three
-// 256-constraint tiles per CU) against the regular one (512-constraint tiles, one per CU).
+// Isotropic bodies, batched work: the register-light tile kernel (no stored B, three
+// 256-constraint tiles per CU in fp64, four in fp32) against the regular one (fp64:
+// 512-constraint tiles, one per CU; fp32: three 256-constraint tiles).
 // Tiles are dispatched in rounds of 3C resp. C, so the better choice depends on how the
 // tile count quantises; per-round times (ms, C3 columns, 100 sweeps) measured on MI355X.
-inline bool iso_schedule_pays(long m, int cu) {
+inline bool iso_schedule_pays(long m, int cu, int precision) {
   const long t = (m + 255) / 256;                       // 256-constraint tiles
+  if (precision == EGS_F32) return t > 3L * cu;         // fp32: 4 instead of 3 tiles per CU (C4: +7 %)
   if (t < 2L * cu) return false;                       // fewer than two tiles per CU: registers are not the limit
   const long full3 = t / (3L * cu), rem3 = t % (3L * cu);
   const double iso = 0.66 * full3 + (rem3 == 0 ? 0.0 : rem3 <= cu ? 0.45 : rem3 <= 2L * cu ? 0.57 : 0.66);
@@ -302,8 +304,11 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.resume = resume;
     a.max_slots = quad ? p->planq.max_slots : p->plan.max_slots;
     a.spin_limit = kSpinLimit;
-    a.iso = (p->minv_iso && p->precision == EGS_F64 && !quad && p->plan.block == 256 &&
-             iso_schedule_pays(p->m, ctx->cu_count)) ? 1 : 0;
+    a.iso = (p->minv_iso && !quad && p->plan.block == 256 && iso_schedule_pays(p->m, ctx->cu_count, p->precision)) ? 1 : 0;
+    {
+      const char *ie = std::getenv("EGS_ISO");   // 2: force the variant wherever the bodies allow it (experiments)
+      if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256) a.iso = 1;
+    }
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
       launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
@@ -623,7 +628,7 @@ void ensure_tile_plan(egs_problem *p) {
     // Oversize islands (patch / global kernels) always use 256 -- unless 512 makes every island fit.
     const char *te = std::getenv("EGS_TILE");   // experiment knob: 64/128/256/512 constraints per tile
     const int forced = te ? std::atoi(te) : 0;
-    int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints && !(p->minv_iso && p->precision == EGS_F64 && iso_schedule_pays(m, p->ctx->cu_count)) ? 512 : 256);
+    int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints && p->precision == EGS_F64 && !(p->minv_iso && iso_schedule_pays(m, p->ctx->cu_count, p->precision)) ? 512 : 256);
     p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), tile);
     if (!forced && !p->plan.global.empty()) {
       if (tile == 256) {   // islands of 257..512 constraints: one 512-thread workgroup, all hand-offs in LDS

@@ -76,7 +76,7 @@ __device__ __forceinline__ bool ordered_accumulate(REAL *s_acc, unsigned *s_tick
 // three wavefronts per SIMD instead of two, i.e. 768 instead of 512 constraints resident
 // per CU.  Same products, same roundings, same bits.
 template <typename REAL, int BLOCK, int METHOD, bool ISO>
-__global__ void __launch_bounds__(BLOCK, ISO ? 3 : 1) tile_solve_kernel(const SolveArgs<REAL> A) {
+__global__ void __launch_bounds__(BLOCK, ISO ? (sizeof(REAL) == 4 ? 4 : 3) : 1) tile_solve_kernel(const SolveArgs<REAL> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
   unsigned *s_tick = reinterpret_cast<unsigned *>(smem + (size_t)A.max_slots * 6 * sizeof(REAL));
