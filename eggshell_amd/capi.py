@@ -21,7 +21,7 @@ JOINT_BALL, CONTACT_BOX = 0, 1
 EXPORTS = [
     "egs_default_params", "egs_context_create", "egs_context_destroy", "egs_last_error",
     "egs_context_synchronize", "egs_timer_start", "egs_timer_stop", "egs_kernel_time",
-    "egs_solve_blocks", "egs_problem_create", "egs_problem_destroy", "egs_problem_set_blocks",
+    "egs_solve_blocks", "egs_problem_create", "egs_problem_create_batch", "egs_problem_destroy", "egs_problem_set_blocks",
     "egs_problem_solve", "egs_problem_get_lambda", "egs_problem_get_accumulators",
     "egs_problem_set_state", "egs_problem_set_constraints", "egs_problem_assemble",
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
@@ -188,6 +188,23 @@ class Problem:
         ctx.check(load().egs_problem_create(ctx.h, C.c_int32(self.n), C.c_int32(self.m), _p(self.body0),
                                             _p(self.body1), C.c_int32(precision), C.byref(self.h)))
         ctx._children.add(self)
+
+    @classmethod
+    def batch(cls, ctx, n_bodies, n_constraints, body0, body1, precision=F64):
+        """E independent ensembles in one problem (egs_problem_create_batch): per-ensemble
+        sizes and ensemble-LOCAL body indices; returns (problem, body_offset, constraint_offset)."""
+        nb, nc = _i32(n_bodies), _i32(n_constraints)
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.body0, self.body1 = _i32(body0), _i32(body1)     # local indices, as passed
+        self.n, self.m = int(nb.sum()), int(nc.sum())
+        boff = np.zeros(nb.shape[0] + 1, np.int32); coff = np.zeros(nb.shape[0] + 1, np.int32)
+        self.h = C.c_void_p()
+        ctx.check(load().egs_problem_create_batch(ctx.h, C.c_int32(nb.shape[0]), _p(nb), _p(nc), _p(self.body0),
+                                                  _p(self.body1), C.c_int32(precision), C.byref(self.h),
+                                                  _p(boff), _p(coff)))
+        ctx._children.add(self)
+        return self, boff, coff
 
     def close(self):
         if self.h:

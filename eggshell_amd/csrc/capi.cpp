@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdint>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -756,6 +757,45 @@ egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int3
   if (st != EGS_OK) { delete p; return st; }
   *out = p;
   return EGS_OK;
+}
+
+egs_status egs_problem_create_batch(egs_context *ctx, int32_t n_ensembles, const int32_t *n_bodies,
+                                    const int32_t *n_constraints, const int32_t *body0, const int32_t *body1,
+                                    int32_t precision, egs_problem **out, int32_t *body_offset,
+                                    int32_t *constraint_offset) {
+  if (!ctx || !out) return EGS_ERR_INVALID;
+  *out = nullptr;
+  if (n_ensembles < 0 || (n_ensembles > 0 && (!n_bodies || !n_constraints)))
+    return fail(ctx, EGS_ERR_INVALID, "bad ensemble count / NULL size tables");
+  long nb = 0, nc = 0;
+  for (int e = 0; e < n_ensembles; ++e) {
+    if (n_bodies[e] < 0 || n_constraints[e] < 0) return fail(ctx, EGS_ERR_INVALID, "negative ensemble size");
+    nb += n_bodies[e]; nc += n_constraints[e];
+  }
+  if (nb > INT32_MAX || nc > INT32_MAX) return fail(ctx, EGS_ERR_INVALID, "batch too large for 32-bit indices");
+  if (nc > 0 && (!body0 || !body1)) return fail(ctx, EGS_ERR_INVALID, "NULL topology");
+  std::vector<int32_t> g0, g1;
+  try {
+    g0.resize((size_t)nc); g1.resize((size_t)nc);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, EGS_ERR_HIP, "host allocation failed");
+  }
+  long bo = 0, co = 0;
+  for (int e = 0; e < n_ensembles; ++e) {
+    if (body_offset) body_offset[e] = (int32_t)bo;
+    if (constraint_offset) constraint_offset[e] = (int32_t)co;
+    for (int i = 0; i < n_constraints[e]; ++i) {
+      const int32_t a = body0[co + i], b = body1[co + i];
+      if (a < -1 || a >= n_bodies[e] || b < -1 || b >= n_bodies[e])
+        return fail(ctx, EGS_ERR_INVALID, "ensemble-local body index out of range");
+      g0[(size_t)(co + i)] = a < 0 ? -1 : (int32_t)(bo + a);
+      g1[(size_t)(co + i)] = b < 0 ? -1 : (int32_t)(bo + b);
+    }
+    bo += n_bodies[e]; co += n_constraints[e];
+  }
+  if (body_offset) body_offset[n_ensembles] = (int32_t)bo;
+  if (constraint_offset) constraint_offset[n_ensembles] = (int32_t)co;
+  return egs_problem_create(ctx, (int32_t)nb, (int32_t)nc, g0.data(), g1.data(), precision, out);
 }
 
 void egs_problem_destroy(egs_problem *p) {

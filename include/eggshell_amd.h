@@ -118,6 +118,19 @@ egs_status egs_solve_blocks(egs_context *ctx, int32_t n_bodies,
 egs_status egs_problem_create(egs_context *ctx, int32_t n_bodies, int32_t m,
                               const int32_t *body0, const int32_t *body1,
                               int32_t precision, egs_problem **out);
+/* Batched form (BASELINE config 4: 1024 independent 64-body
+ * ensembles): E ensembles in ONE problem.  body0/body1 hold the E constraint
+ * lists back to back with ensemble-LOCAL body indices (-1 = world); the
+ * returned offset tables ([E+1] each, may be NULL) say where ensemble e's
+ * bodies and constraints live in the concatenated arrays every other
+ * egs_problem_* call takes.  Ensembles never share a body, so each is its own
+ * set of islands and results equal E separate solves bit for bit; one launch
+ * sweeps them all. */
+egs_status egs_problem_create_batch(egs_context *ctx, int32_t n_ensembles,
+                                    const int32_t *n_bodies, const int32_t *n_constraints,
+                                    const int32_t *body0, const int32_t *body1,
+                                    int32_t precision, egs_problem **out,
+                                    int32_t *body_offset, int32_t *constraint_offset);
 void egs_problem_destroy(egs_problem *p);
 /* upload the flat system of entry 1 (any pointer may be NULL = keep) */
 egs_status egs_problem_set_blocks(egs_problem *p, const double *Minv,

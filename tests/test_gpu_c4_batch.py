@@ -39,3 +39,34 @@ def test_c4_full_batch_fp32(ctx):
         x64, _, _, _ = orc.fast_iterate(s, rhs[rows], 0.01, orc.GAUSS_SEIDEL, max_iters=50, tol=0.0)
         assert np.abs(lam[rows] - x64).max() <= 2e-3 * max(1.0, np.abs(x64).max())
     pr.close()
+
+
+def test_batched_creation_equals_separate_solves(ctx):
+    """egs_problem_create_batch (ensemble-local indices + offset tables): every ensemble of
+    the batch gets the bits of its own separate solve; bad local indices are rejected."""
+    from helpers import system_from_scene
+    rng = np.random.default_rng(7)
+    ens = [scenes.box_stack(2, 2, 3, jitter=1e-3, seed=1), scenes.chain(9), scenes.box_stack(3, 2, 2), scenes.chain(1)]
+    systems = [system_from_scene(e)[0] for e in ens]
+    rhs = [rng.uniform(-1, 1, 3 * s.m) for s in systems]
+    pr, boff, coff = capi.Problem.batch(ctx, [s.n for s in systems], [s.m for s in systems],
+                                        np.concatenate([s.body0 for s in systems]),
+                                        np.concatenate([s.body1 for s in systems]))
+    assert boff.tolist() == np.concatenate([[0], np.cumsum([s.n for s in systems])]).tolist()
+    assert coff.tolist() == np.concatenate([[0], np.cumsum([s.m for s in systems])]).tolist()
+    cat = lambda name: np.concatenate([getattr(s, name) for s in systems])
+    pr.set_blocks(cat("Minv"), cat("J0"), cat("J1"), cat("is_eq"), cat("lo"), cat("hi"), np.concatenate(rhs))
+    prm = capi.params(method=capi.SOR, max_iters=40, tol=0.0, cfm=0.05)
+    st = pr.solve(prm)
+    x = pr.lambda_()
+    pr.close()
+    assert st.status == capi.OK
+    for e, s in enumerate(systems):
+        one = capi.Problem(ctx, s.n, s.body0, s.body1)
+        one.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs[e])
+        one.solve(prm)
+        assert np.array_equal(one.lambda_(), x[3 * coff[e]:3 * coff[e + 1]])
+        one.close()
+    with pytest.raises(capi.EgsError) as err:
+        capi.Problem.batch(ctx, [2, 2], [1, 1], [0, 2], [1, 0])      # local index 2 in a 2-body ensemble
+    assert err.value.status == capi.ERR_INVALID
