@@ -23,7 +23,7 @@ EXPORTS = [
     "egs_context_synchronize", "egs_timer_start", "egs_timer_stop", "egs_kernel_time",
     "egs_solve_blocks", "egs_problem_create", "egs_problem_create_batch", "egs_problem_destroy", "egs_problem_set_blocks",
     "egs_problem_solve", "egs_problem_get_lambda", "egs_problem_get_accumulators",
-    "egs_problem_set_state", "egs_problem_set_constraints", "egs_problem_assemble",
+    "egs_problem_set_state", "egs_problem_set_mass", "egs_problem_set_constraints", "egs_problem_assemble",
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
     "egs_problem_advance", "egs_problem_get_state",
     "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
@@ -188,6 +188,10 @@ class Problem:
         ctx.check(load().egs_problem_create(ctx.h, C.c_int32(self.n), C.c_int32(self.m), _p(self.body0),
                                             _p(self.body1), C.c_int32(precision), C.byref(self.h)))
         ctx._children.add(self)
+
+    def set_mass(self, inv_mass, inv_inertia):
+        """Compact M^-1: 1/m [n] and the inverse global-frame inertia [n][9]."""
+        self.ctx.check(load().egs_problem_set_mass(self.h, _p(_f64(inv_mass)), _p(_f64(inv_inertia))))
 
     @classmethod
     def batch(cls, ctx, n_bodies, n_constraints, body0, body1, precision=F64):

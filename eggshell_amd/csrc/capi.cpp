@@ -853,6 +853,23 @@ egs_status egs_problem_set_state(egs_problem *p, const double *pos, const double
   });
 }
 
+egs_status egs_problem_set_mass(egs_problem *p, const double *inv_mass, const double *inv_inertia) {
+  if (!p) return EGS_ERR_INVALID;
+  if (p->n > 0 && (!inv_mass || !inv_inertia)) return fail(p->ctx, EGS_ERR_INVALID, "NULL mass arrays");
+  return guarded(p->ctx, [&]() -> egs_status {
+    const size_t n = (size_t)p->n;
+    std::vector<double> blocks(n * 36, 0.0);
+    for (size_t b = 0; b < n; ++b) {
+      double *W = blocks.data() + b * 36;
+      for (int k = 0; k < 3; ++k) W[7 * k] = inv_mass[b];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) W[6 * (3 + r) + 3 + c] = inv_inertia[b * 9 + 3 * r + c];
+    }
+    if (n) { upload(p->Minv_d, blocks.data(), n * 36, p->ctx->stream); p->minv_r_valid = false; }
+    return EGS_OK;
+  });
+}
+
 egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind, const double *data) {
   if (!p) return EGS_ERR_INVALID;
   if (p->m > 0 && (!kind || !data)) return fail(p->ctx, EGS_ERR_INVALID, "NULL constraint descriptors");

@@ -160,6 +160,11 @@ egs_status egs_problem_set_state(egs_problem *p, const double *pos,
                                  const double *R, const double *v,
                                  const double *w, const double *Minv,
                                  const double *f_ext);
+/* The compact form of Minv: per body 1/m and the 3x3 inverse of the
+ * global-frame inertia, row-major -- all ConstructMassInertiaMatrixInverse
+ * (ensembles.cc:202-212) ever stores; the 6x6 blocks are built from it. */
+egs_status egs_problem_set_mass(egs_problem *p, const double *inv_mass,
+                                const double *inv_inertia);
 egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind,
                                        const double *data);
 /* J, err, bounds, rhs = -(erp/dt^2) err - J (v/dt + Minv f_ext) on device */

@@ -207,3 +207,22 @@ def test_advance_matches_oracle_position_update(ctx):
     assert np.abs(pos - po).max() <= 1e-15 and np.abs(R - Ro).max() <= 1e-15
     assert np.array_equal(v, v6[:, :3]) and np.array_equal(w, v6[:, 3:])
     pr.close()
+
+
+def test_compact_mass_entry_equals_full_blocks(ctx):
+    """egs_problem_set_mass (1/m + 3x3 inverse inertia per body, all that
+    ConstructMassInertiaMatrixInverse stores) gives the step of the 6x6 blocks."""
+    sc = scenes.chain(8)
+    pr, Minv, f_ext = make_problem(ctx, sc)
+    prm = capi.params(method=capi.SOR, max_iters=60, tol=0.0, cfm=0.0)
+    pr.step(1e-3, 0.2, prm)
+    v_full, lam_full = pr.velocity(), pr.lambda_()
+    pr.close()
+    blocks = Minv.reshape(-1, 6, 6)
+    pr = capi.Problem(ctx, sc["p"].shape[0], sc["body0"], sc["body1"])
+    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], None, f_ext)
+    pr.set_mass(blocks[:, 0, 0].copy(), blocks[:, 3:, 3:].reshape(-1, 9).copy())
+    pr.set_constraints(sc["kind"], sc["data"])
+    pr.step(1e-3, 0.2, prm)
+    assert np.array_equal(pr.velocity(), v_full) and np.array_equal(pr.lambda_(), lam_full)
+    pr.close()
