@@ -593,7 +593,7 @@ struct Collider::Impl {
     ~G() { if (p) (void)hipFree(p); }
   };
   G<int> gcount, goff, ccount, coff, cand, flags, blocks, pi, pj, pcount, poff, blocks2, b0, b1;
-  G<int> coords, bucket_of, arrival, tcount, toff, sorted, blocks3;   // uniform grid
+  G<int> coords, bucket_of, arrival, tcount, toff, sorted, blocks3, scratch;   // uniform grid
   G<double> data, cell;
 };
 
@@ -610,41 +610,44 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
   n_ground_ = 0; n_pairs_ = 0;
   if (n <= 0) return 0;
   const size_t nn = (size_t)n;
-  I.gcount.need(nn); I.goff.need(nn); I.ccount.need(nn); I.coff.need(nn); I.cand.need(nn * KMAX); I.flags.need(2);
-  I.blocks.need((nn + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
-  HIPCHK(hipMemsetAsync(I.flags.p, 0, 2 * sizeof(int), s));
+  I.gcount.need(nn); I.goff.need(nn); I.ccount.need(nn); I.coff.need(nn); I.cand.need(nn * KMAX); I.flags.need(4);
+  I.blocks.need((nn + SCAN_CHUNK - 1) / SCAN_CHUNK + 8); I.blocks2.need((nn + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
+  // flags: [0] candidate overflow, [1] ground contacts, [2] candidate pairs, [3] pair contacts
+  HIPCHK(hipMemsetAsync(I.flags.p, 0, 4 * sizeof(int), s));
   const int gb = (n + 255) / 256;
   hipLaunchKernelGGL(ground_kernel, dim3(gb), dim3(256), 0, s, n, dpos, dR, dside, (const int *)nullptr, I.gcount.p,
                      (int *)nullptr, (int *)nullptr, (double *)nullptr);
-  const int G = exclusive_scan(s, n, I.gcount.p, I.goff.p, I.blocks.p, I.flags.p + 1);
+  exclusive_scan_async(s, n, I.gcount.p, I.goff.p, I.blocks.p, I.flags.p + 1);
   if (use_grid(n)) {
     int table = 1024;
     while (table < 2 * n) table <<= 1;
     I.cell.need(1); I.coords.need(nn * 3); I.bucket_of.need(nn); I.arrival.need(nn); I.sorted.need(nn);
     I.tcount.need((size_t)table); I.toff.need((size_t)table); I.blocks3.need((size_t)table / SCAN_CHUNK + 8);
+    I.scratch.need(1);
     HIPCHK(hipMemsetAsync(I.tcount.p, 0, (size_t)table * sizeof(int), s));
     hipLaunchKernelGGL(cell_size_kernel, dim3(1), dim3(1024), 0, s, n, dside, I.cell.p);
     hipLaunchKernelGGL(cell_bin_kernel, dim3(gb), dim3(256), 0, s, n, dpos, I.cell.p, table - 1, I.coords.p, I.bucket_of.p,
                        I.arrival.p, I.tcount.p);
-    exclusive_scan_async(s, table, I.tcount.p, I.toff.p, I.blocks3.p, I.flags.p + 1);
+    exclusive_scan_async(s, table, I.tcount.p, I.toff.p, I.blocks3.p, I.scratch.p);
     hipLaunchKernelGGL(cell_fill_kernel, dim3(gb), dim3(256), 0, s, n, I.bucket_of.p, I.arrival.p, I.toff.p, I.sorted.p);
     hipLaunchKernelGGL(cand_grid_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.coords.p, table - 1, I.toff.p,
                        I.tcount.p, I.sorted.p, I.cand.p, I.ccount.p, I.flags.p);
   } else {
     hipLaunchKernelGGL(cand_kernel, dim3(n), dim3(64), 0, s, n, dpos, dside, I.cand.p, I.ccount.p, I.flags.p);
   }
-  const int C = exclusive_scan(s, n, I.ccount.p, I.coff.p, I.blocks.p, I.flags.p + 1);
-  int overflow = 0;
-  HIPCHK(hipMemcpyAsync(&overflow, I.flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  exclusive_scan_async(s, n, I.ccount.p, I.coff.p, I.blocks2.p, I.flags.p + 2);
+  int totals[4] = {0, 0, 0, 0};   // ONE read-back for overflow, G and C
+  HIPCHK(hipMemcpyAsync(totals, I.flags.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (overflow) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
+  if (totals[0]) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
+  const int G = totals[1], C = totals[2];
   int P = 0;
   if (C > 0) {
     I.pi.need(C); I.pj.need(C); I.pcount.need(C); I.poff.need(C); I.blocks2.need(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
     hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, I.cand.p, I.ccount.p, I.coff.p, I.pi.p, I.pj.p);
     hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
                        (const int *)nullptr, 0, I.pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr, jl);
-    P = exclusive_scan(s, C, I.pcount.p, I.poff.p, I.blocks2.p, I.flags.p + 1);
+    P = exclusive_scan(s, C, I.pcount.p, I.poff.p, I.blocks2.p, I.flags.p + 3);
   }
   const int m = G + P;
   n_ground_ = G; n_pairs_ = C;
