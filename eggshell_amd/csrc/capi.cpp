@@ -179,6 +179,10 @@ struct egs_problem {
   DevBuf<unsigned char> gB0, gB1, gD, gden, gdx;  // cross-workgroup workspace
   DevBuf<uint8_t> is_eq;
   DevBuf<int32_t> error_flag;
+  // per-sweep history of a chunk of sweeps (tolerance-terminated solves, see kernels.h)
+  DevBuf<unsigned char> hist_x, hist_acc;
+  DevBuf<double> hist_out;
+  int hist_sweeps = 0;        // 0: off for the next launch; k: record k sweeps
   bool have_blocks = false, have_state = false, have_constraints = false, minv_r_valid = false;
   bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
@@ -306,9 +310,15 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.max_slots = quad ? p->planq.max_slots : p->plan.max_slots;
     a.spin_limit = kSpinLimit;
     a.iso = (p->minv_iso && !quad && p->plan.block == 256 && iso_schedule_pays(p->m, ctx->cu_count, p->precision)) ? 1 : 0;
+    a.n_bodies = p->n;
+    if (p->hist_sweeps > 0) {   // the isotropic variant has no registers to spare for it
+      a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
+      a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
+      a.iso = 0;
+    }
     {
       const char *ie = std::getenv("EGS_ISO");   // 2: force the variant wherever the bodies allow it (experiments)
-      if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256) a.iso = 1;
+      if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256 && p->hist_sweeps == 0) a.iso = 1;
     }
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
@@ -436,6 +446,18 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
 }
 
+template <typename REAL>
+void fill_history_args(egs_problem *p, SolveArgs<REAL> &a, REAL cfm) {
+  a.J0 = reinterpret_cast<const REAL *>(p->J0.p); a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
+  a.body0 = p->body0.p; a.body1 = p->body1.p;
+  a.is_eq = p->is_eq.p;
+  a.lo = reinterpret_cast<const REAL *>(p->lo.p); a.hi = reinterpret_cast<const REAL *>(p->hi.p);
+  a.rhs = reinterpret_cast<const REAL *>(p->rhs.p);
+  a.wres = reinterpret_cast<REAL *>(p->wres.p);
+  a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p); a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
+  a.m = p->m; a.n_bodies = p->n; a.cfm = cfm;
+}
+
 // The solve driver: sparse_iterations.cc:148-226.
 egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats *stats) {
   egs_context *ctx = p->ctx;
@@ -471,18 +493,90 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     }
     return EGS_OK;
   }
-  // tol > 0: x0 = rhs, residual before iterating, then chunks of check_every
+  // tol > 0: x0 = rhs, residual before iterating, then the reference's loop: one sweep,
+  // one residual, stop at the first err <= tol (sparse_iterations.cc:204-221).
   const int every = prm->check_every > 0 ? prm->check_every : 1;
   int it = 0, flag = 0;
   launch_solve(p, *prm, 0, 0);
   launch_residual(p);
   double err = read_residual(p, &flag);
-  while (!flag && err > prm->tol && it < prm->max_iters) {
-    const int chunk = std::min(every, prm->max_iters - it);
-    launch_solve(p, *prm, chunk, 1);
-    launch_residual(p);
-    err = read_residual(p, &flag);
-    it += chunk;
+  // Fast form, same result: sweeps run in chunks of up to 64 per launch while the kernels
+  // record x and the per-body accumulators after every sweep; one more kernel evaluates the
+  // stopping test of every recorded sweep and ONE read-back per chunk finds the first sweep
+  // that satisfies it.  (Tile and 4-lane kernels; Jacobi and oversize islands use the
+  // sweep-per-launch loop below.)
+  const bool quad = p->use_quad && prm->method != EGS_JACOBI;
+  const bool history = prm->method != EGS_JACOBI && (quad || p->plan.global.empty()) && prm->max_iters > 1;
+  if (history) {
+    const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
+    const size_t per_sweep = (3 * m + 6 * n) * rs;
+    int K = (int)std::min<size_t>(64, std::max<size_t>(1, (size_t(256) << 20) / per_sweep));
+    K = std::min(K, prm->max_iters);
+    p->hist_x.alloc((size_t)K * 3 * m * rs);
+    p->hist_acc.alloc((size_t)K * 6 * n * rs);
+    p->hist_out.alloc((size_t)K * kResidualBlocks * 4);
+    // bodies without constraints never get a snapshot written: theirs stays zero
+    HIPCHK(hipMemsetAsync(p->hist_acc.p, 0, (size_t)K * 6 * n * rs, ctx->stream));
+    std::vector<double> part((size_t)K * kResidualBlocks * 4);
+    while (!flag && err > prm->tol && it < prm->max_iters) {
+      const int chunk = std::min(K, prm->max_iters - it);
+      p->hist_sweeps = chunk;
+      launch_solve(p, *prm, chunk, 1);
+      p->hist_sweeps = 0;
+      auto residual_pass = [&](int write_sweep) {
+        if (p->precision == EGS_F32) {
+          SolveArgs<float> a{};
+          fill_history_args(p, a, (float)prm->cfm);
+          launch_hist_residual<float>(a, chunk, kResidualBlocks, p->hist_out.p, write_sweep, ctx->stream);
+        } else {
+          SolveArgs<double> a{};
+          fill_history_args(p, a, prm->cfm);
+          launch_hist_residual<double>(a, chunk, kResidualBlocks, p->hist_out.p, write_sweep, ctx->stream);
+        }
+      };
+      residual_pass(0);
+      int32_t f32 = 0;
+      HIPCHK(hipMemcpyAsync(part.data(), p->hist_out.p, (size_t)chunk * kResidualBlocks * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(&f32, p->error_flag.p, sizeof f32, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      flag = f32;
+      if (flag) break;
+      int stop = 0;   // first recorded sweep (1-based) at which the reference would stop
+      double err_stop = 0, err_last = err;
+      for (int sw = 1; sw <= chunk; ++sw) {
+        const bool checked = ((it + sw) % every == 0) || (it + sw == prm->max_iters);
+        if (!checked) continue;
+        double sum[4] = {0, 0, 0, 0};
+        const double *ps = part.data() + (size_t)(sw - 1) * kResidualBlocks * 4;
+        for (int b = 0; b < kResidualBlocks; ++b)
+          for (int k = 0; k < 4; ++k) sum[k] += ps[4 * b + k];
+        const double e = std::sqrt(sum[0]) + (std::sqrt(sum[1]) + std::sqrt(sum[2]) + std::sqrt(sum[3]));
+        err_last = e;
+        if (e <= prm->tol) { stop = sw; err_stop = e; break; }
+      }
+      if (stop > 0 && stop < chunk) {
+        // the answer is the snapshot of sweep `stop`: lambda, accumulators, w
+        const size_t off_x = (size_t)(stop - 1) * 3 * m * rs, off_a = (size_t)(stop - 1) * 6 * (size_t)p->n * rs;
+        HIPCHK(hipMemcpyAsync(p->x.p, p->hist_x.p + off_x, 3 * m * rs, hipMemcpyDeviceToDevice, ctx->stream));
+        if (p->n > 0)
+          HIPCHK(hipMemcpyAsync(p->acc.p, p->hist_acc.p + off_a, 6 * (size_t)p->n * rs, hipMemcpyDeviceToDevice, ctx->stream));
+        residual_pass(stop);
+        it += stop;
+        err = err_stop;
+        break;
+      }
+      it += chunk;
+      err = err_last;
+      if (stop == chunk) break;   // the launch's own epilogue state is the answer
+    }
+  } else {
+    while (!flag && err > prm->tol && it < prm->max_iters) {
+      const int chunk = std::min(every, prm->max_iters - it);
+      launch_solve(p, *prm, chunk, 1);
+      launch_residual(p);
+      err = read_residual(p, &flag);
+      it += chunk;
+    }
   }
   p->last_iterations = it;
   if (stats) {

@@ -32,6 +32,14 @@ struct SolveArgs {
   int32_t sweeps, resume, max_slots;
   uint32_t spin_limit;
   int iso = 0;              // 1: every M^-1 block is diag(a,a,a,b,b,b): B is formed on the fly (tile kernel)
+  // Per-sweep history (tolerance-terminated solves): x after sweep s and each body's
+  // accumulator once its last constraint of sweep s has run, s = 1..sweeps of this launch.
+  // hist_residual then evaluates the reference's per-iteration stopping test for the
+  // whole chunk from these snapshots: one launch and one read-back per chunk instead of
+  // one per sweep.  NULL = off.
+  REAL *hist_x = nullptr;      // [sweeps][m][3]
+  REAL *hist_acc = nullptr;    // [sweeps][n_bodies][6]
+  int32_t n_bodies = 0;
 };
 
 template <typename REAL>
@@ -94,6 +102,11 @@ template <typename REAL>
 void launch_velocity(int n, const double *v, const double *w,
                      const double *Minv, const double *f_ext, const REAL *acc,
                      double dt, double *v6, hipStream_t s);
+// Residual partial sums (the 4 categories of sparse_iterations.cc:51-69, `blocks` partial
+// sums each, same reduction order as launch_residual_partials) for every sweep of a recorded
+// chunk: out [sweeps][blocks][4].  write_sweep >= 1 also stores that sweep's w into wres.
+template <typename REAL>
+void launch_hist_residual(const SolveArgs<REAL> &a, int sweeps, int blocks, double *out, int write_sweep, hipStream_t s);
 template <typename REAL>
 void launch_convert_minv(int count, const double *src, REAL *dst, hipStream_t s);
 // *flag (preset to 1) is cleared unless every 6x6 block is exactly diag(a, a, a, b, b, b)

@@ -166,6 +166,20 @@ __global__ void __launch_bounds__(BLOCK, ISO ? (sizeof(REAL) == 4 ? 4 : 3) : 1) 
         if (has1) store_tick(tk1, want1 + 1);
         // the workgroup's sleeping wavefronts poll now instead of when their s_sleep expires
         asm volatile("s_wakeup");
+        if (!ISO && A.hist_x) {   // snapshots for the per-sweep stopping test (kernels.h)
+          REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
+          hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+          if (has0 && ord0 == cnt0 - 1u) {      // this was body0's last update of the sweep
+            REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + slot_body[slot0]) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ha[k] = a0[k];
+          }
+          if (has1 && ord1 == cnt1 - 1u) {
+            REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + slot_body[slot1]) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ha[k] = a1[k];
+          }
+        }
         want0 += cnt0; want1 += cnt1;
         spins = 0;
         alive = ++sweep <= A.sweeps;
@@ -227,6 +241,50 @@ __global__ void __launch_bounds__(256) residual_partials_kernel(int rows, const 
     __syncthreads();
   }
   if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// The same four sums for every sweep of a recorded chunk (SolveArgs::hist_x / hist_acc):
+// w = cfm x + J a - rhs from the snapshots, evaluated with the solve kernels' own epilogue
+// expression, then the reduction of residual_partials_kernel -- so each sweep's value is the
+// one a launch stopped after that sweep would have produced, bit for bit.
+template <typename REAL>
+__global__ void __launch_bounds__(256) hist_residual_kernel(const SolveArgs<REAL> A, double *out, int write_sweep) {
+  __shared__ double red[4][256];
+  const int sweep = blockIdx.y;          // 0-based
+  const REAL *hx = A.hist_x + (size_t)sweep * A.m * 3;
+  const REAL *ha = A.hist_acc + (size_t)sweep * A.n_bodies * 6;
+  const int rows = 3 * A.m;
+  double e = 0, a = 0, b = 0, c = 0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+    const int i = r / 3, rr = r - 3 * i;
+    const int b0 = A.body0[i], b1 = A.body1[i];
+    REAL j0[6], j1[6], a0[6], a1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      j0[k] = b0 >= 0 ? A.J0[(size_t)i * 18 + 6 * rr + k] : REAL(0);
+      j1[k] = b1 >= 0 ? A.J1[(size_t)i * 18 + 6 * rr + k] : REAL(0);
+      a0[k] = b0 >= 0 ? ha[(size_t)b0 * 6 + k] : REAL(0);
+      a1[k] = b1 >= 0 ? ha[(size_t)b1 * 6 + k] : REAL(0);
+    }
+    const REAL xv = hx[r], l = A.lo[r], h = A.hi[r];
+    const REAL wr = tfma(A.cfm, xv, row_dot(j0, a0, j1, a1)) - A.rhs[r];
+    if (write_sweep == sweep + 1) A.wres[r] = wr;
+    const double w = (double)wr;
+    if (A.is_eq[r]) e += w * w;
+    else {
+      if (xv == l && w < 0) a += w * w;
+      if (xv == h && w > 0) b += w * w;
+      if (xv > l && xv < h) c += w * w;
+    }
+  }
+  red[0][threadIdx.x] = e; red[1][threadIdx.x] = a; red[2][threadIdx.x] = b; red[3][threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[((size_t)sweep * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 // --------------------------------------------------------------------------
@@ -731,6 +789,12 @@ void launch_residual_partials(int rows, const REAL *wres, const REAL *x, const R
 }
 
 template <typename REAL>
+void launch_hist_residual(const SolveArgs<REAL> &a, int sweeps, int blocks, double *out, int write_sweep, hipStream_t s) {
+  if (sweeps <= 0 || a.m <= 0) return;
+  hipLaunchKernelGGL((hist_residual_kernel<REAL>), dim3(blocks, sweeps), dim3(256), 0, s, a, out, write_sweep);
+}
+
+template <typename REAL>
 void launch_velocity(int n, const double *v, const double *w, const double *Minv, const double *f_ext,
                      const REAL *acc, double dt, double *v6, hipStream_t s) {
   if (n <= 0) return;
@@ -808,7 +872,8 @@ void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s) {
   template void launch_velocity<REAL>(int, const double *, const double *, const double *, const double *,   \
                                       const REAL *, double, double *, hipStream_t);                          \
   template void launch_convert_minv<REAL>(int, const double *, REAL *, hipStream_t);                         \
-  template void launch_minv_iso<REAL>(int, const REAL *, int *, hipStream_t);
+  template void launch_minv_iso<REAL>(int, const REAL *, int *, hipStream_t);                               \
+  template void launch_hist_residual<REAL>(const SolveArgs<REAL> &, int, int, double *, int, hipStream_t);
 EGS_INSTANTIATE(double)
 EGS_INSTANTIATE(float)
 

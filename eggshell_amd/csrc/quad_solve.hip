@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
           xn = project(tfma(t0, inv[0], x[0]), eq[0], lo[0], hi[0]);
           dx[0] = xn - x[0]; x[0] = xn;
         }
+        REAL an_hist[3] = {REAL(0), REAL(0), REAL(0)};
         if (has) {
           REAL an[3];
 #pragma unroll
@@ -274,6 +275,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             REAL u = tfma(Bh[3 * k + 0], dx[0], a[k]);
             u = tfma(Bh[3 * k + 1], dx[1], u);
             an[k] = tfma(Bh[3 * k + 2], dx[2], u);
+            an_hist[k] = an[k];
           }
           if (sh) {
 #pragma unroll
@@ -284,6 +286,17 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
           } else {
             store3(acc_addr, an);
             if (half == 0) store_tick(tick_addr, want + 1u);
+          }
+        }
+        if (!PATCH && A.hist_x) {   // snapshots for the per-sweep stopping test (kernels.h)
+          if (q == 0) {
+            REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
+            hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+          }
+          if (has && ord == cnt - 1u) {   // this was the body's last update of the sweep
+            const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
+            REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
+            ha[0] = an_hist[0]; ha[1] = an_hist[1]; ha[2] = an_hist[2];
           }
         }
         // 1024-thread tiles: 16 wavefronts share one LDS; the idle ones sleep (see kernels.hip).

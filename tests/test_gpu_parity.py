@@ -273,3 +273,30 @@ def test_isotropic_fast_path_has_the_same_bits(ctx, method, monkeypatch):
     x, a, st = gpu_solve(ctx, s2, rhs, 0.02, method, 30)
     xf, af, _, _ = orc.fast_iterate(s2, rhs, 0.02, method, max_iters=30, tol=0.0)
     assert same_bits(x, xf) and same_bits(a, af)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_tolerance_terminated_runs_stop_where_the_reference_stops(ctx, method, monkeypatch):
+    """tol > 0 (the reference's default loop: one sweep, one residual, stop at the first
+    err <= tol): sweeps run in recorded chunks on the device; sweep count, lambda,
+    accumulators and the residual equal the oracle's sweep-by-sweep loop -- for the 4-lane
+    and the 1-lane kernels, fp64 and fp32, check_every > 1, and runs that hit max_iters."""
+    rng = np.random.default_rng(45)
+    cases = [system_from_scene(scenes.chain(12))[0], system_from_scene(scenes.box_stack(3, 3, 4))[0],
+             random_system(rng, 30, 120, world_frac=0.1)[0]]
+    for quad in ("1", "0"):
+        monkeypatch.setenv("EGS_QUAD", quad)
+        for s in cases:
+            rhs = rng.uniform(-1, 1, 3 * s.m)
+            for cfm, tol, max_iters, every in ((0.5, 1e-9, 500, 1), (0.5, 1e-6, 500, 7), (0.05, 1e-9, 70, 1), (0.5, 1e-9, 65, 1)):
+                x, a, st = gpu_solve(ctx, s, rhs, cfm, method, max_iters, tol=tol, check_every=every)
+                xf, af, it, rf = orc.fast_iterate(s, rhs, cfm, method, max_iters=max_iters, tol=tol, check_every=every)
+                assert st.iterations == it, (quad, cfm, tol, max_iters, every, st.iterations, it)
+                assert same_bits(x, xf) and same_bits(a, af)
+                assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+    monkeypatch.setenv("EGS_QUAD", "1")
+    s = cases[1]
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    x32, a32, st = gpu_solve(ctx, s, rhs, 0.5, method, 300, tol=1e-4, precision=capi.F32)
+    xo, ao, it, _ = orc.fast_iterate_f32(s, rhs, 0.5, method, max_iters=300, tol=1e-4)
+    assert st.iterations == it and same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
