@@ -62,6 +62,10 @@ struct egs_context {
   // hipEvent pairs around every solve-kernel launch
   std::vector<hipEvent_t> kev;
   size_t kev_used = 0;
+  // egs_solve_blocks is stateless for its caller, but a simulation calls it every step with
+  // the same constraint graph: the last problem (schedule + device buffers) is kept and reused
+  // when n, m, precision and body0/body1 are unchanged (4.6 -> 0.7 ms per call at C3).
+  egs_problem *oneshot = nullptr;
 };
 
 namespace {
@@ -661,6 +665,7 @@ void egs_context_destroy(egs_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->oneshot) { egs_problem_destroy(ctx->oneshot); ctx->oneshot = nullptr; }
   for (auto e : ctx->kev) if (e) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -1071,14 +1076,21 @@ egs_status egs_solve_blocks(egs_context *ctx, int32_t n, const double *Minv, int
   if (!ctx) return EGS_ERR_INVALID;
   if (m > 0 && (!Minv || !J0 || !J1 || !is_eq || !lo || !hi || !rhs || !x))
     return fail(ctx, EGS_ERR_INVALID, "NULL array");
-  egs_problem *p = nullptr;
-  egs_status st = egs_problem_create(ctx, n, m, body0, body1, precision, &p);
-  if (st != EGS_OK) return st;
+  egs_problem *p = ctx->oneshot;
+  const bool reuse = p && p->n == n && p->m == m && p->precision == precision &&
+                     (m == 0 || (std::memcmp(p->h_body0.data(), body0, (size_t)m * sizeof(int32_t)) == 0 &&
+                                 std::memcmp(p->h_body1.data(), body1, (size_t)m * sizeof(int32_t)) == 0));
+  egs_status st = EGS_OK;
+  if (!reuse) {
+    if (p) { egs_problem_destroy(p); ctx->oneshot = nullptr; }
+    st = egs_problem_create(ctx, n, m, body0, body1, precision, &p);
+    if (st != EGS_OK) return st;
+    ctx->oneshot = p;
+  }
   st = egs_problem_set_blocks(p, Minv, J0, J1, is_eq, lo, hi, rhs);
   egs_solve_stats local;
   if (st == EGS_OK) st = egs_problem_solve(p, params, stats ? stats : &local);
   if (st == EGS_OK && m > 0) st = egs_problem_get_lambda(p, x);
-  egs_problem_destroy(p);
   return st;
 }
 

@@ -300,3 +300,23 @@ def test_tolerance_terminated_runs_stop_where_the_reference_stops(ctx, method, m
     x32, a32, st = gpu_solve(ctx, s, rhs, 0.5, method, 300, tol=1e-4, precision=capi.F32)
     xo, ao, it, _ = orc.fast_iterate_f32(s, rhs, 0.5, method, max_iters=300, tol=1e-4)
     assert st.iterations == it and same_bits(x32.astype(np.float32), xo) and same_bits(a32.astype(np.float32), ao)
+
+
+def test_one_shot_entry_is_stateless_although_it_reuses_its_schedule(ctx):
+    """egs_solve_blocks keeps the last schedule and device buffers for the next call with the
+    same constraint graph; results never depend on what was solved before."""
+    rng = np.random.default_rng(46)
+    sA, rhsA = random_system(rng, 12, 40, world_frac=0.2)
+    sB, rhsB = random_system(rng, 9, 25, world_frac=0.2)
+    prm = capi.params(method=capi.SOR, max_iters=30, tol=0.0, cfm=0.05)
+
+    def one_shot(s, rhs):
+        return ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, prm)[0]
+
+    ref = {}
+    for key, (s, rhs) in {"A": (sA, rhsA), "B": (sB, rhsB), "A2": (sA, -0.5 * rhsA)}.items():
+        ref[key] = gpu_solve(ctx, s, rhs, 0.05, capi.SOR, 30)[0]
+    assert same_bits(one_shot(sA, rhsA), ref["A"])
+    assert same_bits(one_shot(sA, -0.5 * rhsA), ref["A2"])      # same graph: schedule reused
+    assert same_bits(one_shot(sB, rhsB), ref["B"])              # other graph: rebuilt
+    assert same_bits(one_shot(sA, rhsA), ref["A"])

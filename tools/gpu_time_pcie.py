@@ -21,7 +21,7 @@ for _ in range(3): ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_e
 t = time.perf_counter(); N = 20
 for _ in range(N): x, st = ctx.solve_blocks(s.Minv, s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs, prm)
 dt = (time.perf_counter() - t) / N
-print(f"one-shot egs_solve_blocks C3: {dt*1e3:.2f} ms per call = {1/dt:.0f} calls/s (plan+alloc+H2D 6.2 MB+solve+D2H)")
+print(f"one-shot egs_solve_blocks C3: {dt*1e3:.2f} ms per call = {1/dt:.0f} calls/s (H2D 6.2 MB+solve+D2H; schedule reused from the previous call)")
 pr = capi.Problem(ctx, s.n, s.body0, s.body1)
 t = time.perf_counter()
 for _ in range(N):
