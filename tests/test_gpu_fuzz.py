@@ -1,0 +1,53 @@
+"""GPU (-m gpu): randomised sweep over topologies, sizes, methods, precisions and schedules;
+every case must give the oracle's bits.  Catches ordering bugs that the hand-picked scenes
+miss (waits between wavefronts, tile boundaries, world-only constraints, bodies with many
+constraints)."""
+import numpy as np
+import pytest
+
+from eggshell_amd import capi
+from helpers import random_system
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run(ctx, s, rhs, method, K, cfm, precision):
+    pr = capi.Problem(ctx, s.n, s.body0, s.body1, precision)
+    pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+    st = pr.solve(capi.params(method=method, max_iters=K, tol=0.0, cfm=cfm))
+    x, a = pr.lambda_(), pr.accumulators()
+    pr.close()
+    return x, a, st
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_systems_all_schedules(ctx, seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(20):
+        n = int(rng.integers(2, 160))
+        m = int(rng.integers(1, 1500))
+        s, rhs = random_system(rng, n, m, world_frac=float(rng.uniform(0, 0.5)), eq_frac=float(rng.uniform(0, 1)),
+                               connected=bool(rng.integers(0, 2)))
+        if case % 4 == 3:      # isotropic mass blocks: the tile kernel that forms B on the fly
+            w = np.zeros((n, 6, 6))
+            for b in range(n):
+                a_, b_ = rng.uniform(0.2, 3.0, 2)
+                w[b] = np.diag([a_, a_, a_, b_, b_, b_])
+            s = orc.Sys(w.reshape(n, 36), s.body0, s.body1, s.J0, s.J1, s.is_eq, s.lo, s.hi)
+        monkeypatch.setenv("EGS_ISO", "2" if case % 4 == 3 else "1")
+        method = int(rng.choice([capi.JACOBI, capi.GAUSS_SEIDEL, capi.SOR]))
+        K = int(rng.integers(0, 25))
+        cfm = float(rng.choice([0.0, 0.01, 0.3]))
+        xf, af, _, _ = orc.fast_iterate(s, rhs, cfm, method, max_iters=K, tol=0.0)
+        xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, cfm, method, max_iters=K)
+        for quad, patch, qpatch in (("1", "1", "1"), ("0", "1", "0"), ("0", "0", "1")):
+            monkeypatch.setenv("EGS_QUAD", quad)
+            monkeypatch.setenv("EGS_PATCH", patch)
+            monkeypatch.setenv("EGS_QUAD_PATCH", qpatch)
+            x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64)
+            assert st.status == capi.OK
+            assert np.array_equal(x, xf) and np.array_equal(a, af), (seed, case, n, m, method, K, quad, patch)
+        monkeypatch.setenv("EGS_QUAD", "1"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
+        x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F32)
+        assert np.array_equal(x.astype(np.float32), xo) and np.array_equal(a.astype(np.float32), ao), (seed, case, "f32")
