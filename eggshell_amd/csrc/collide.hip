@@ -547,9 +547,34 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int n, const int *in, c
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
+// n <= 16384: the whole scan in one 1024-thread workgroup (one launch instead of three)
+constexpr int SCAN_SMALL = 16384;
+__global__ void __launch_bounds__(1024) scan_small_kernel(int n, const int *in, int *out, int *total) {
+  __shared__ int part[1024];
+  const int per = (n + 1023) / 1024;            // contiguous elements per thread, <= 16
+  const int base = threadIdx.x * per;
+  int v[16], sum = 0;
+  for (int k = 0; k < per; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; sum += v[k]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {          // inclusive Hillis-Steele over the 1024 partial sums
+    const int add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;            // exclusive prefix of this thread's chunk
+  for (int k = 0; k < per; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+  if (threadIdx.x == 1023) *total = part[1023];
+}
+
 void exclusive_scan_async(hipStream_t s, int n, const int *in, int *out, int *scratch_blocks, int *total_d) {
   const int nblocks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   if (n <= 0) return;
+  if (n <= SCAN_SMALL) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, s, n, in, out, total_d);
+    return;
+  }
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1), 0, s, nblocks, scratch_blocks, total_d);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(256), 0, s, n, in, scratch_blocks, out);
