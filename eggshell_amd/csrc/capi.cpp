@@ -187,6 +187,7 @@ struct egs_problem {
   DevBuf<unsigned char> hist_x, hist_acc;
   DevBuf<double> hist_out;
   int hist_sweeps = 0;        // 0: off for the next launch; k: record k sweeps
+  bool residual_pending = false;   // wres/x hold a finished solve whose residual sums were not reduced yet
   bool have_blocks = false, have_state = false, have_constraints = false, minv_r_valid = false;
   bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
@@ -485,10 +486,11 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
       launch_solve(p, *prm, chunk, done > 0 ? 1 : 0);
       done += chunk;
     } while (done < prm->max_iters);
-    launch_residual(p);
     p->last_iterations = prm->max_iters;
+    p->residual_pending = !stats;   // nobody is looking: the reduction runs when egs_problem_get_stats asks
     if (stats) {
       int flag = 0;
+      launch_residual(p);
       stats->residual = read_residual(p, &flag);
       stats->iterations = prm->max_iters;
       stats->status = flag ? EGS_ERR_STALL : EGS_OK;
@@ -573,6 +575,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
       err = err_last;
       if (stop == chunk) break;   // the launch's own epilogue state is the answer
     }
+    p->residual_pending = it > 0;   // res_partials still hold the sums of x0; x / wres are final
   } else {
     while (!flag && err > prm->tol && it < prm->max_iters) {
       const int chunk = std::min(every, prm->max_iters - it);
@@ -1063,6 +1066,7 @@ egs_status egs_problem_get_stats(egs_problem *p, egs_solve_stats *stats) {
     stats->iterations = p->last_iterations;
     if (p->m == 0) return EGS_OK;
     int flag = 0;
+    if (p->residual_pending) { launch_residual(p); p->residual_pending = false; }
     stats->residual = read_residual(p, &flag);
     stats->status = flag ? EGS_ERR_STALL : EGS_OK;
     return flag ? fail(p->ctx, EGS_ERR_STALL, "device ordering wait timed out") : EGS_OK;

@@ -320,3 +320,18 @@ def test_one_shot_entry_is_stateless_although_it_reuses_its_schedule(ctx):
     assert same_bits(one_shot(sA, -0.5 * rhsA), ref["A2"])      # same graph: schedule reused
     assert same_bits(one_shot(sB, rhsB), ref["B"])              # other graph: rebuilt
     assert same_bits(one_shot(sA, rhsA), ref["A"])
+
+
+def test_get_stats_after_the_fact(ctx):
+    """egs_problem_get_stats reports the residual of the last solve whether or not the solve
+    call itself asked for statistics (fixed sweeps and tolerance-terminated)."""
+    rng = np.random.default_rng(47)
+    s, rhs = random_system(rng, 20, 60, world_frac=0.2)
+    for tol, K in ((0.0, 15), (1e-9, 500)):
+        pr = capi.Problem(ctx, s.n, s.body0, s.body1)
+        pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+        pr.solve(capi.params(method=capi.SOR, max_iters=K, tol=tol, cfm=0.3), want_stats=False)
+        st = pr.stats()
+        pr.close()
+        _, _, it, rf = orc.fast_iterate(s, rhs, 0.3, capi.SOR, max_iters=K, tol=tol)
+        assert st.iterations == it and abs(st.residual - rf) <= 1e-12 * max(1.0, rf), (tol, st.residual, rf)
