@@ -410,6 +410,209 @@ __global__ void __launch_bounds__(1024) murty_check_kernel(int n, const double *
   }
 }
 
+// ---- small problems: the whole pivot loop in ONE workgroup ----------------------
+// The reference's own ensembles give the dense solver a few dozen rows (Cairn(4): 3 rows per
+// contact), where a launch and a read-back per pivot dwarf the arithmetic.  For n <= 112 the
+// principal submatrix A(S,S) fits LDS in packed lower-triangular form, so one 256-thread
+// workgroup runs the reference's complete loop (lcp.cc:157-274: flip the first offender,
+// factor A(S,S) afresh, solve, w, CheckMurtySolution, best-solution memory, iteration cap and
+// the final looser check) without the host.  Same decisions as murty_device below.
+constexpr int kSmallMurtyMax = 112;
+
+struct SmallMurtyResult {   // written by thread 0 at the end
+  int solved;               // a solution at 1e-9 (lcp.cc:196) or, when capped, at 1e-8 (lcp.cc:244-246)
+  int pivots;
+  int not_spd;              // a principal submatrix had a non-positive pivot
+  int pad;
+};
+
+__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // c <= r
+
+__global__ void __launch_bounds__(256) murty_small_kernel(int n, const double *A, const double *bvec, const double *lo_g,
+                                                          const double *hi_g, int box_fix, int max_iterations,
+                                                          double *x_out, double *w_out, SmallMurtyResult *res) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *T = sm;                                   // packed lower triangle of A(S,S), then its Cholesky factor
+  double *x = T + kSmallMurtyMax * (kSmallMurtyMax + 1) / 2;
+  double *w = x + kSmallMurtyMax, *r = w + kSmallMurtyMax, *Cv = r + kSmallMurtyMax, *lo = Cv + kSmallMurtyMax;
+  double *hi = lo + kSmallMurtyMax, *b = hi + kSmallMurtyMax, *y = b + kSmallMurtyMax, *bx = y + kSmallMurtyMax;
+  double *bw = bx + kSmallMurtyMax, *y2 = bw + kSmallMurtyMax;
+  __shared__ int idx[kSmallMurtyMax];
+  __shared__ unsigned char S[kSmallMurtyMax];
+  __shared__ int s_first, s_oob, s_wbad, s_ns, s_state, s_fail;   // s_state: 0 run, 1 solved, 2 capped
+  __shared__ double s_resid2, s_good, s_best;
+  const int tid = threadIdx.x;
+  const int NONE = 0x7fffffff;
+
+  for (int i = tid; i < n; i += 256) {
+    S[i] = 1; lo[i] = lo_g[i]; hi[i] = hi_g[i]; Cv[i] = lo_g[i]; b[i] = bvec[i];
+    x[i] = 0.0; w[i] = -bvec[i]; r[i] = -bvec[i];   // lcp.cc:184-185
+    bx[i] = 0.0; bw[i] = -bvec[i];
+  }
+  if (tid == 0) { s_state = 0; s_fail = 0; }
+  __syncthreads();
+
+  // CheckMurtySolution (lcp.cc:20-103) + goodness (lcp.cc:107-113) of the current x, w, r
+  auto check = [&]() {
+    if (tid == 0) { s_first = NONE; s_oob = 0; s_wbad = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const double xi = x[i], wi = w[i];
+      bool off;
+      if (S[i]) off = (xi < lo[i]) || (xi > hi[i]);
+      else off = (Cv[i] == lo[i] && wi < 0) || (Cv[i] == hi[i] && wi > 0);
+      if (off) atomicMin(&s_first, i);
+      if (xi < lo[i] || xi > hi[i]) s_oob = 1;
+      if ((xi == lo[i] && wi < 0) || (xi == hi[i] && wi > 0)) s_wbad = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double res2 = 0.0, good = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double d = r[i] - w[i];
+        res2 += d * d;
+        if (!(x[i] > 0)) good += x[i];
+        if (!(w[i] > 0)) good += w[i];
+      }
+      s_resid2 = res2; s_good = good;
+    }
+    __syncthreads();
+  };
+  auto is_solution = [&](double tol) { return s_first == NONE && !s_oob && !s_wbad && sqrt(s_resid2) <= tol; };
+  // (A x)_i with two threads per row (even / odd columns) and four independent chains each;
+  // the pair is combined through LDS by the caller
+  auto row_times_x = [&](int i, int half) {
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    const double *row = A + (size_t)i * n;
+    int c = half;
+    for (; c + 6 < n; c += 8) {
+      p0 = __builtin_fma(row[c], x[c], p0);
+      p1 = __builtin_fma(row[c + 2], x[c + 2], p1);
+      p2 = __builtin_fma(row[c + 4], x[c + 4], p2);
+      p3 = __builtin_fma(row[c + 6], x[c + 6], p3);
+    }
+    for (; c < n; c += 2) p0 = __builtin_fma(row[c], x[c], p0);
+    return (p0 + p1) + (p2 + p3);
+  };
+  // r = A x - b
+  auto residual_vector = [&]() {
+    const int i = tid >> 1, half = tid & 1;
+    double part = 0.0;
+    if (i < n) part = row_times_x(i, half);
+    if (i < n && half == 1) y2[i] = part;
+    __syncthreads();
+    if (i < n && half == 0) r[i] = (part + y2[i]) - b[i];
+    __syncthreads();
+  };
+
+  check();
+  if (tid == 0) s_best = s_good;
+  __syncthreads();
+
+  int iter = 0, pivots = 0;
+  bool force = box_fix != 0;
+  while (iter < max_iterations) {
+    if (!force) {
+      if (is_solution(1e-9)) { if (tid == 0) s_state = 1; __syncthreads(); break; }
+      if (tid == 0 && s_first != NONE) {             // lcp.cc:36-62: flip the first offender
+        const int i = s_first;
+        if (S[i]) { S[i] = 0; Cv[i] = (x[i] < lo[i]) ? lo[i] : hi[i]; }
+        else S[i] = 1;
+      }
+      __syncthreads();
+    }
+    force = false;
+    if (tid == 0) {                                  // index list of S
+      int ns = 0;
+      for (int i = 0; i < n; ++i) if (S[i]) idx[ns++] = i;
+      s_ns = ns;
+    }
+    for (int i = tid; i < n; i += 256) x[i] = S[i] ? 0.0 : Cv[i];   // x = x_clamped
+    __syncthreads();
+    const int ns = s_ns;
+    // right-hand side: b(S), minus A(S,!S) x(!S) for the true box problem (lcp.cc:199-216)
+    if (box_fix) {
+      residual_vector();                              // r = A x_clamped - b
+      for (int k = tid; k < ns; k += 256) y[k] = -r[idx[k]];
+    } else {
+      for (int k = tid; k < ns; k += 256) y[k] = b[idx[k]];
+    }
+    for (int e = tid; e < ns * (ns + 1) / 2; e += 256) {             // gather A(S,S), lower triangle
+      int rr = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while (tri(rr + 1, 0) <= e) ++rr;
+      while (tri(rr, 0) > e) --rr;
+      const int cc = e - tri(rr, 0);
+      T[e] = A[(size_t)idx[rr] * n + idx[cc]];
+    }
+    __syncthreads();
+    // Cholesky, right-looking, in place; y rides along as an extra row, so L z = y is solved by
+    // the same column steps.  Two barriers per column: every thread takes the square root of the
+    // (not yet overwritten) pivot itself.
+    for (int j = 0; j < ns; ++j) {
+      const double d = T[tri(j, j)];
+      if (!(d > 0.0)) { if (tid == 0) s_fail = 1; }
+      const double rt = sqrt(d > 0.0 ? d : 1.0);
+      for (int i = j + 1 + tid; i < ns; i += 256) T[tri(i, j)] /= rt;
+      if (tid == 255) y[j] /= rt;
+      __syncthreads();
+      if (tid == 0) T[tri(j, j)] = rt;
+      const int tx = tid & 15, ty = tid >> 4;
+      for (int i = j + 1 + ty; i < ns; i += 16) {
+        const double lij = T[tri(i, j)];
+        for (int k = j + 1 + tx; k <= i; k += 16) T[tri(i, k)] = __builtin_fma(-lij, T[tri(k, j)], T[tri(i, k)]);
+      }
+      {
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < ns; i += 256) y[i] = __builtin_fma(-T[tri(i, j)], yj, y[i]);
+      }
+      __syncthreads();
+    }
+    // L^T v = z in ONE wavefront (two unknowns per lane), no workgroup barrier per step
+    if (tid < 64) {
+      for (int j = ns - 1; j >= 0; --j) {
+        if (tid == (j & 63)) y[j] = y[j] / T[tri(j, j)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double yj = y[j];
+        for (int i = tid; i < j; i += 64) y[i] = __builtin_fma(-T[tri(j, i)], yj, y[i]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < ns; k += 256) x[idx[k]] = y[k];
+    __syncthreads();
+    residual_vector();                               // r = A x - b
+    for (int i = tid; i < n; i += 256) w[i] = S[i] ? 0.0 : r[i];     // lcp.cc:219-223
+    __syncthreads();
+    ++pivots;
+    check();
+    if (s_good > s_best) {                           // lcp.cc:125-137 (uniform: shared value)
+      for (int i = tid; i < n; i += 256) { bx[i] = x[i]; bw[i] = w[i]; }
+      __syncthreads();
+      if (tid == 0) s_best = s_good;
+      __syncthreads();
+    }
+    ++iter;
+    if (s_fail) break;
+  }
+  int solved = (s_state == 1);
+  if (!solved && !s_fail) {
+    // capped: the best-seen iterate (reference rule only), re-checked at the looser 1e-8 (lcp.cc:241-246)
+    if (!box_fix) {
+      for (int i = tid; i < n; i += 256) { x[i] = bx[i]; w[i] = bw[i]; }
+      __syncthreads();
+    }
+    residual_vector();
+    check();
+    solved = is_solution(1e-8) ? 1 : 0;
+  }
+  for (int i = tid; i < n; i += 256) { x_out[i] = x[i]; w_out[i] = w[i]; }
+  if (tid == 0) { res->solved = solved; res->pivots = pivots; res->not_spd = s_fail; res->pad = 0; }
+}
+
 template <typename T>
 struct Buf {
   T *p = nullptr;
@@ -455,6 +658,23 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   if (n == 0) return true;
   const double p2 = std::pow(2.0, n);
   const int max_iterations = block ? 4 * n + 100 : (p2 > 1000 ? 1000 : (int)p2);  // lcp.cc:168
+  if (n <= kSmallMurtyMax && !block) {   // the whole loop in one workgroup, one read-back
+    Buf<double> lo_s(n), hi_s(n);
+    Buf<SmallMurtyResult> res_d(1);
+    SmallMurtyResult res{};
+    HIPCHK(hipMemcpyAsync(lo_s.p, lo.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(hi_s.p, hi.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    const size_t lds = (size_t)(kSmallMurtyMax * (kSmallMurtyMax + 1) / 2 + 11 * kSmallMurtyMax) * sizeof(double);
+    hipLaunchKernelGGL(murty_small_kernel, dim3(1), dim3(256), lds, s, n, dA, db, lo_s.p, hi_s.p, box_fix ? 1 : 0,
+                       max_iterations, dx, dw, res_d.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&res, res_d.p, sizeof res, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *pivots_out = res.pivots;
+    if (res.not_spd) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
+    if (!res.solved && msg) *msg = "MurtyPrincipalPivot: iteration cap reached without a sensible solution (lcp.cc:250-252)";
+    return res.solved != 0;
+  }
   const int npad_max = (n + NB - 1) / NB * NB;
   Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
   Buf<uint8_t> S_d(n);

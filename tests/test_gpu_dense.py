@@ -114,3 +114,29 @@ def test_config5_size_properties(ctx):
         assert abs(x[~eq] @ w[~eq]) < 1e-6
     else:
         assert piv >= 1000
+
+
+@pytest.mark.parametrize("dim", [2, 63, 111, 112, 113])
+def test_single_workgroup_loop_boundary(ctx, dim):
+    """Up to 112 inequality rows the whole pivot loop runs in one workgroup (one launch, one
+    read-back); 113 takes the launch-per-pivot path.  Same pivot count and answer as the
+    oracle on both sides of the switch; box semantics too."""
+    rng = np.random.default_rng(300 + dim)
+    A = _spd(rng, dim) + 0.2 * np.eye(dim)
+    b = rng.uniform(-1, 1, dim)
+    none = np.zeros(dim, np.uint8)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, none, np.zeros(dim), np.full(dim, INF))
+    oko, xo, wo, pivo = orc.murty(A, b)
+    assert ok and oko and piv == pivo
+    assert np.abs(x - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max()) and np.abs(w - wo).max() <= 1e-8 * max(1.0, np.abs(wo).max())
+    lo, hi = np.full(dim, -0.3), np.full(dim, 0.4)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, none, lo, hi, use_bounds=1)
+    oko, xo, wo, pivo = orc.mixed_constraints(A, b, none, lo, hi, use_bounds=1)
+    assert ok and oko and piv == pivo and np.abs(x - xo).max() <= 1e-8 and np.abs(w - wo).max() <= 1e-8
+
+
+def test_single_workgroup_loop_reports_indefinite_matrix(ctx):
+    """A(S,S) not positive definite: failure, not a wrong answer (as on the large path)."""
+    A = np.array([[1.0, 2.0], [2.0, 1.0]])       # symmetric, eigenvalues 3 and -1
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, np.array([1.0, 1.0]), np.zeros(2, np.uint8), np.zeros(2), np.full(2, INF))
+    assert not ok
