@@ -102,7 +102,9 @@ __device__ __forceinline__ void store3(unsigned acc_addr, const float (&a)[3]) {
 // vmcnt(0) -> sc1 ticket store / sc1 ticket poll -> sc1 loads, as in
 // patch_solve_kernel.  w = A x - rhs is then left to a follow-up kernel (the
 // shared accumulators are final only when every patch has finished).
-template <typename REAL, int METHOD, int QT, bool PATCH>
+// HIST = true: records the per-sweep snapshots of SolveArgs::hist_x / hist_acc (tolerance-
+// terminated solves); a separate instantiation, so the plain kernel keeps its 96 VGPRs.
+template <typename REAL, int METHOD, int QT, bool PATCH, bool HIST>
 __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL> A, uint32_t *g_tick) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             if (half == 0) store_tick(tick_addr, want + 1u);
           }
         }
-        if (!PATCH && A.hist_x) {   // snapshots for the per-sweep stopping test (kernels.h)
+        if (HIST) {   // snapshots for the per-sweep stopping test (kernels.h)
           if (q == 0) {
             REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
             hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
@@ -353,12 +355,16 @@ void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int ti
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
   uint32_t *none = nullptr;
+  const bool hist = a.hist_x != nullptr;
+#define EGS_QLAUNCH(METHOD, QT, HIST) \
+  hipLaunchKernelGGL((quad_solve_kernel<REAL, METHOD, QT, false, HIST>), dim3(n_tiles), dim3(4 * QT), lds, s, a, none)
   if (tile_size == 64) {
-    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 64, false>), dim3(n_tiles), dim3(256), lds, s, a, none);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 64, false>), dim3(n_tiles), dim3(256), lds, s, a, none);
+    if (method == 1) { if (hist) EGS_QLAUNCH(1, 64, true); else EGS_QLAUNCH(1, 64, false); }
+    else { if (hist) EGS_QLAUNCH(2, 64, true); else EGS_QLAUNCH(2, 64, false); }
   } else if (tile_size == 256) {
-    if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, false>), dim3(n_tiles), dim3(1024), lds, s, a, none);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, false>), dim3(n_tiles), dim3(1024), lds, s, a, none);
+    if (method == 1) { if (hist) EGS_QLAUNCH(1, 256, true); else EGS_QLAUNCH(1, 256, false); }
+    else { if (hist) EGS_QLAUNCH(2, 256, true); else EGS_QLAUNCH(2, 256, false); }
+#undef EGS_QLAUNCH
   } else {
     throw std::invalid_argument("launch_quad_solve: tile size must be 64 or 256");
   }
@@ -371,8 +377,8 @@ template <typename REAL>
 void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s) {
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
-  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
 }
 
 template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
