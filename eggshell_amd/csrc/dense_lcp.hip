@@ -5,10 +5,10 @@
 // Structure (all matrices row-major fp64, resident in HBM for the whole call):
 //   * One routine does every factorisation: a blocked right-looking Cholesky of
 //     the first `nf` columns of a lower-trapezoid T (extra rows below the square
-//     part ride along).  Per 64-column block: chol_panel_kernel (diagonal block
-//     factored in LDS by one wavefront, triangular solve of every 64-row slab
-//     below it) and chol_update_kernel (trailing T -= P P^T on the fp64 matrix
-//     cores, v_mfma_f64_16x16x4_f64).
+//     part ride along).  Per 64-column block: chol_diag_kernel (diagonal block
+//     and its inverse, in registers), chol_trsm_kernel (panel below = B L11^-T
+//     as a matrix product) and chol_update_kernel (trailing T -= P P^T), the
+//     last two on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
 //   * MixedConstraintsSolver: permute to [E | I], append b as a last row and
 //     factor only the E columns: the trailing block IS the Schur complement
 //     A_ii - A_ie A_ee^-1 A_ei, the trailing part of the b row IS
@@ -19,7 +19,8 @@
 //     (lcp.cc:202-203): gather + Cholesky + back substitution on the device;
 //     the flip decision, best-solution memory (lcp.cc:105-137) and the
 //     iteration cap min(1000, 2^dim) (lcp.cc:168) are evaluated per pivot from
-//     a 64-byte record read back from the device.
+//     a 64-byte record read back from the device.  Up to 112 rows the whole
+//     loop runs in one workgroup instead (murty_small_kernel).
 // The reference factors with Eigen's pivoted LDLT / LU inverse; A is required
 // to be symmetric with positive definite A_ee and A(S,S) (true for J M^-1 J^T
 // + cfm I and for the reference's own tests); otherwise the call reports

@@ -243,45 +243,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 }
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
-                                       unsigned &t1, double (&a0)[6], double (&a1)[6]) {
-  d2_t u0, u1, u2, v0, v1, v2;
-  asm volatile(
-      "ds_read_b32 %0, %8\n\t"
-      "ds_read_b32 %1, %9\n\t"
-      "ds_read_b128 %2, %10\n\t"
-      "ds_read_b128 %3, %10 offset:16\n\t"
-      "ds_read_b128 %4, %10 offset:32\n\t"
-      "ds_read_b128 %5, %11\n\t"
-      "ds_read_b128 %6, %11 offset:16\n\t"
-      "ds_read_b128 %7, %11 offset:32\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
-      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
-      : "memory");
-  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
-  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
-}
-__device__ __forceinline__ void poll12(unsigned tk0, unsigned tk1, unsigned ac0, unsigned ac1, unsigned &t0,
-                                       unsigned &t1, float (&a0)[6], float (&a1)[6]) {
-  f2_t u0, u1, u2, v0, v1, v2;
-  asm volatile(
-      "ds_read_b32 %0, %8\n\t"
-      "ds_read_b32 %1, %9\n\t"
-      "ds_read_b64 %2, %10\n\t"
-      "ds_read_b64 %3, %10 offset:8\n\t"
-      "ds_read_b64 %4, %10 offset:16\n\t"
-      "ds_read_b64 %5, %11\n\t"
-      "ds_read_b64 %6, %11 offset:8\n\t"
-      "ds_read_b64 %7, %11 offset:16\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(v0), "=&v"(v1), "=&v"(v2)
-      : "v"(tk0), "v"(tk1), "v"(ac0), "v"(ac1)
-      : "memory");
-  a0[0] = u0.x; a0[1] = u0.y; a0[2] = u1.x; a0[3] = u1.y; a0[4] = u2.x; a0[5] = u2.y;
-  a1[0] = v0.x; a1[1] = v0.y; a1[2] = v1.x; a1[3] = v1.y; a1[4] = v2.x; a1[5] = v2.y;
-}
-// two-stage variant: tickets only (8 bytes per lane instead of 104) ...
+// two-stage poll: tickets only (8 bytes per lane instead of 104) ...
 __device__ __forceinline__ void poll_ticks(unsigned tk0, unsigned tk1, unsigned &t0, unsigned &t1) {
   asm volatile(
       "ds_read_b32 %0, %2\n\t"
