@@ -614,6 +614,7 @@ __device__ __forceinline__ void gload_cons(const GlobalArgs<REAL> &A, int g, con
     c.lo[r] = A.lo[(size_t)d.cidx * 3 + r];
     c.hi[r] = A.hi[(size_t)d.cidx * 3 + r];
     c.eq[r] = A.is_eq[(size_t)d.cidx * 3 + r] != 0;
+    clamp_bounds(c.eq[r], c.lo[r], c.hi[r]);
   }
 }
 

@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       lo[r] = A.lo[c * 3 + r];
       hi[r] = A.hi[c * 3 + r];
       eq[r] = A.is_eq[c * 3 + r] != 0;
+      clamp_bounds(eq[r], lo[r], hi[r]);
       x[r] = A.resume ? A.x[c * 3 + r] : rhs[r];
     }
   }
@@ -248,25 +249,25 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         }
         if (METHOD == 1) {
           REAL t0 = res[0];
-          REAL xn = project(tfma(t0, inv[0], x[0]), eq[0], lo[0], hi[0]);
+          REAL xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
           dx[0] = xn - x[0]; x[0] = xn;
           REAL t1 = tfma(-Dl[0], dx[0], res[1]);
-          xn = project(tfma(t1, inv[1], x[1]), eq[1], lo[1], hi[1]);
+          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
           dx[1] = xn - x[1]; x[1] = xn;
           REAL t2 = tfma(-Dl[1], dx[0], res[2]);
           t2 = tfma(-Dl[2], dx[1], t2);
-          xn = project(tfma(t2, inv[2], x[2]), eq[2], lo[2], hi[2]);
+          xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
           dx[2] = xn - x[2]; x[2] = xn;
         } else {
           REAL t2 = res[2];
-          REAL xn = project(tfma(t2, inv[2], x[2]), eq[2], lo[2], hi[2]);
+          REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
           dx[2] = xn - x[2]; x[2] = xn;
           REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
-          xn = project(tfma(t1, inv[1], x[1]), eq[1], lo[1], hi[1]);
+          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
           dx[1] = xn - x[1]; x[1] = xn;
           REAL t0 = tfma(-Dl[1], dx[2], res[0]);                 // D02
           t0 = tfma(-Dl[0], dx[1], t0);                          // D01
-          xn = project(tfma(t0, inv[0], x[0]), eq[0], lo[0], hi[0]);
+          xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
           dx[0] = xn - x[0]; x[0] = xn;
         }
         REAL an_hist[3] = {REAL(0), REAL(0), REAL(0)};

@@ -40,13 +40,19 @@ __device__ __forceinline__ T row_dot(const T *j0, const T *a0, const T *j1, cons
 }
 
 // sparse_iterations_utils.cc:12-21, branch-free: same result for every input
-// (NaN compares false and passes through, as in the reference).
+// (NaN compares false and passes through, as in the reference).  Equality rows carry
+// lo = -inf, hi = +inf in registers (clamp_bounds below), for which the two selects
+// return x itself -- one select pair less on the dependent chain of every row.
 template <typename T>
-__device__ __forceinline__ T project(T x, bool eq, T lo, T hi) {
+__device__ __forceinline__ T project(T x, T lo, T hi) {
   T r = x;
   r = (x > hi) ? hi : r;
   r = (x < lo) ? lo : r;
-  return eq ? x : r;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void clamp_bounds(bool eq, T &lo, T &hi) {
+  if (eq) { lo = -__builtin_huge_val(); hi = __builtin_huge_val(); }
 }
 
 // a += B d, rows applied in order 0,1,2 (oracle acc_add)
@@ -176,6 +182,7 @@ __device__ __forceinline__ void load_cons(const SolveArgs<REAL> &A, int cidx, bo
     c.lo[r] = A.lo[(size_t)cidx * 3 + r];
     c.hi[r] = A.hi[(size_t)cidx * 3 + r];
     c.eq[r] = A.is_eq[(size_t)cidx * 3 + r] != 0;
+    clamp_bounds(c.eq[r], c.lo[r], c.hi[r]);
   }
 }
 
@@ -196,7 +203,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
   if (METHOD == 0) {  // Jacobi: no intra-block coupling
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      REAL xn = project(tfma(res[r], c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(res[r], c.inv[r], x[r]), c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
@@ -206,7 +213,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
       REAL t = res[r];
 #pragma unroll
       for (int l = 0; l < r; ++l) t = tfma(-c.D[3 * r + l], dx[l], t);
-      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
@@ -216,7 +223,7 @@ __device__ __forceinline__ void update_rows(const Cons<REAL> &c, const REAL *res
       REAL t = res[r];
 #pragma unroll
       for (int l = 2; l > r; --l) t = tfma(-c.D[3 * r + l], dx[l], t);
-      REAL xn = project(tfma(t, c.inv[r], x[r]), c.eq[r], c.lo[r], c.hi[r]);
+      REAL xn = project(tfma(t, c.inv[r], x[r]), c.lo[r], c.hi[r]);
       dx[r] = xn - x[r];
       x[r] = xn;
     }
