@@ -1281,13 +1281,15 @@ void egs_world_destroy(egs_world *w) {
 egs_status egs_world_set_bodies(egs_world *w, const double *pos, const double *R, const double *v, const double *wv,
                                 const double *Minv, const double *f_ext, const double *side_lengths) {
   if (!w) return EGS_ERR_INVALID;
-  if (w->n > 0 && (!pos || !R || !v || !wv || !Minv || !f_ext || !side_lengths))
-    return fail(w->ctx, EGS_ERR_INVALID, "NULL array");
+  // the first call needs everything; afterwards NULL = keep (M^-1, f_ext and the side lengths
+  // are frozen at Init in the reference, Q5)
+  if (w->n > 0 && !w->have_bodies && (!pos || !R || !v || !wv || !Minv || !f_ext || !side_lengths))
+    return fail(w->ctx, EGS_ERR_INVALID, "NULL array on the first egs_world_set_bodies");
   return guarded(w->ctx, [&]() -> egs_status {
     if (!w->prob) world_make_problem(w, w->jb0.data(), w->jb1.data(), (int)w->jb0.size());
     egs_status st = egs_problem_set_state(w->prob, pos, R, v, wv, Minv, f_ext);
     if (st != EGS_OK) return st;
-    upload(w->dside, side_lengths, (size_t)w->n * 3, w->ctx->stream);
+    if (side_lengths) upload(w->dside, side_lengths, (size_t)w->n * 3, w->ctx->stream);
     w->have_bodies = true;
     return EGS_OK;
   });

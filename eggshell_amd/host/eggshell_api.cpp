@@ -229,6 +229,7 @@ Ensemble::~Ensemble() {
 }
 
 void Ensemble::Init() {  // ensembles.cc:24-29
+  if (world_) { egs_world_destroy(world_); world_ = nullptr; }   // M^-1 / f_ext are re-sent to a fresh world
   ConstructMassInertiaMatrixInverse();
   InitializeExternalForceTorqueVector();
   VectorXd err = ComputePositionConstraintError();  // CheckInitialConditions, :224-232
@@ -434,6 +435,7 @@ bool Ensemble::StepOnDevice(double dt) {
   }
   if (!detect_contacts && !contacts_.empty()) return false;   // caller-supplied contacts: use the explicit path
   egs_context *ctx = egs::DefaultContext();
+  const bool first = !world_;
   if (!world_) {
     egs::check(egs_world_create(ctx, n_, EGS_F64, &world_));
     world_joints_ = -1;
@@ -450,8 +452,9 @@ bool Ensemble::StepOnDevice(double dt) {
     for (int r = 0; r < 6; ++r)
       for (int c = 0; c < 6; ++c) Minv[(size_t)i * 36 + 6 * r + c] = M_inverse_(6 * i + r, 6 * i + c);
   }
-  egs::check(egs_world_set_bodies(world_, pos.data(), R.data(), vl.data(), w.data(), Minv.data(),
-                                  external_force_torque_.data(), side.data()));
+  // M^-1, the external force and the box sizes are frozen at Init() (Q5): sent once
+  egs::check(egs_world_set_bodies(world_, pos.data(), R.data(), vl.data(), w.data(), first ? Minv.data() : nullptr,
+                                  first ? external_force_torque_.data() : nullptr, first ? side.data() : nullptr));
   if (world_joints_ != mj) {   // joints are permanent (ensembles.cc:331-334)
     egs::check(egs_world_set_joints(world_, mj, jb0.data(), jb1.data(), jdata.data()));
     world_joints_ = mj;

@@ -241,7 +241,9 @@ typedef struct egs_world egs_world;
 egs_status egs_world_create(egs_context *ctx, int32_t n_bodies, int32_t precision, egs_world **out);
 void egs_world_destroy(egs_world *w);
 /* pos [n][3], R [n][9], v, w [n][3], Minv [n][36], f_ext [n][6] (frozen as
- * Ensemble::Init leaves them, quirk Q5), side_lengths [n][3] (body.h:91). */
+ * Ensemble::Init leaves them, quirk Q5), side_lengths [n][3] (body.h:91).
+ * The first call needs every array; later calls may pass NULL for any of them
+ * to keep what the device holds (typically Minv, f_ext, side_lengths). */
 egs_status egs_world_set_bodies(egs_world *w, const double *pos, const double *R, const double *v,
                                 const double *w_ang, const double *Minv, const double *f_ext,
                                 const double *side_lengths);
