@@ -509,10 +509,10 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   // Fast form, same result: sweeps run in chunks of up to 64 per launch while the kernels
   // record x and the per-body accumulators after every sweep; one more kernel evaluates the
   // stopping test of every recorded sweep and ONE read-back per chunk finds the first sweep
-  // that satisfies it.  (Tile and 4-lane kernels; Jacobi and oversize islands use the
-  // sweep-per-launch loop below.)
+  // that satisfies it.  (Tile and 4-lane kernels; oversize islands use the sweep-per-launch
+  // loop below.)
   const bool quad = p->use_quad && prm->method != EGS_JACOBI;
-  const bool history = prm->method != EGS_JACOBI && (quad || p->plan.global.empty()) && prm->max_iters > 1;
+  const bool history = (quad || p->plan.global.empty()) && prm->max_iters > 1;
   if (history) {
     const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
     const size_t per_sweep = (3 * m + 6 * n) * rs;
@@ -558,7 +558,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
           for (int k = 0; k < 4; ++k) sum[k] += ps[4 * b + k];
         const double e = std::sqrt(sum[0]) + (std::sqrt(sum[1]) + std::sqrt(sum[2]) + std::sqrt(sum[3]));
         err_last = e;
-        if (e <= prm->tol) { stop = sw; err_stop = e; break; }
+        if (!(e > prm->tol)) { stop = sw; err_stop = e; break; }   // as the loop condition: a NaN residual stops it too
       }
       if (stop > 0 && stop < chunk) {
         // the answer is the snapshot of sweep `stop`: lambda, accumulators, w

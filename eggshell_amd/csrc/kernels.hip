@@ -134,6 +134,17 @@ __global__ void __launch_bounds__(BLOCK, ISO ? (sizeof(REAL) == 4 ? 4 : 3) : 1) 
                                base0 + (unsigned)(s - 1) * cnt0 + pos0,
                                base1 + (unsigned)(s - 1) * cnt1 + pos1, A.spin_limit);
       __syncthreads();
+      if (!ISO && A.hist_x) {   // snapshots for the per-sweep stopping test: the sweep is complete here
+        if (active) {
+          REAL *hx = A.hist_x + ((size_t)(s - 1) * A.m + d.cidx) * 3;
+          hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+        }
+        for (int q = tid + 1; q < nslots; q += BLOCK) {
+          REAL *ha = A.hist_acc + ((size_t)(s - 1) * A.n_bodies + slot_body[q]) * 6;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ha[k] = s_acc[q * 6 + k];
+        }
+      }
     }
   } else {
     const unsigned ord0 = (METHOD == 2) ? cnt0 - 1u - pos0 : pos0;
