@@ -378,8 +378,14 @@ template <typename REAL>
 void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s) {
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
-  if (method == 1) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-  else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  const bool hist = a.hist_x != nullptr;
+  if (method == 1) {
+    if (hist) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  } else {
+    if (hist) hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
+  }
 }
 
 template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
