@@ -167,7 +167,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   if (block == kAutoQuadBlock) {
     int largest = 0;
     for (int sz : island_size) largest = std::max(largest, sz);
-    block = largest <= 64 ? 64 : 256;
+    block = largest <= 64 ? 64 : (largest <= 128 ? 128 : 256);
     plan.block = block;
   }
 

@@ -56,8 +56,8 @@ struct Plan {
 constexpr uint16_t kSharedSlot = 0xFFFF;
 
 // Throws std::invalid_argument on out-of-range body indices.
-// block = kAutoQuadBlock: 64 when every island fits 64 constraints, else 256
-// (the two tile sizes of the 4-lanes-per-constraint schedule).
+// block = kAutoQuadBlock: the smallest of 64 / 128 / 256 that holds the largest island
+// (the tile sizes of the 4-lanes-per-constraint schedule).
 constexpr int kAutoQuadBlock = 0;
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
                 int block);

@@ -362,12 +362,15 @@ void launch_quad_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int ti
   if (tile_size == 64) {
     if (method == 1) { if (hist) EGS_QLAUNCH(1, 64, true); else EGS_QLAUNCH(1, 64, false); }
     else { if (hist) EGS_QLAUNCH(2, 64, true); else EGS_QLAUNCH(2, 64, false); }
+  } else if (tile_size == 128) {
+    if (method == 1) { if (hist) EGS_QLAUNCH(1, 128, true); else EGS_QLAUNCH(1, 128, false); }
+    else { if (hist) EGS_QLAUNCH(2, 128, true); else EGS_QLAUNCH(2, 128, false); }
   } else if (tile_size == 256) {
     if (method == 1) { if (hist) EGS_QLAUNCH(1, 256, true); else EGS_QLAUNCH(1, 256, false); }
     else { if (hist) EGS_QLAUNCH(2, 256, true); else EGS_QLAUNCH(2, 256, false); }
 #undef EGS_QLAUNCH
   } else {
-    throw std::invalid_argument("launch_quad_solve: tile size must be 64 or 256");
+    throw std::invalid_argument("launch_quad_solve: tile size must be 64, 128 or 256");
   }
 }
 

@@ -215,7 +215,8 @@ def test_quad_schedule_with_256_constraint_tiles(ctx, method):
     1024-thread tiles; same bits as the oracle (fp64 and fp32)."""
     rng = np.random.default_rng(41)
     cases = [system_from_scene(scenes.concat([scenes.chain(int(k)) for k in (65, 200, 256, 3, 130, 90, 17)]))[0],
-             random_system(rng, 40, 230, world_frac=0.1)[0]]
+             random_system(rng, 40, 230, world_frac=0.1)[0],
+             system_from_scene(scenes.concat([scenes.chain(int(k)) for k in (65, 128, 100, 7, 128)]))[0]]   # 128-constraint tiles
     for s in cases:
         rhs = rng.uniform(-1, 1, 3 * s.m)
         for K in (1, 7, 60):
