@@ -205,36 +205,57 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   // Constraints with equal (level mod D) are therefore ready TOGETHER; putting
   // them in the same wavefront turns 1/D lane utilisation into nearly full
   // wavefronts that take turns (EGS_LANE_ORDER=0 restores island-major order).
-  std::vector<int32_t> level(m, 0), phase(m, 0);
+  std::vector<int32_t> phase(m, 0);
+  int max_phase = 0;
   {
-    std::vector<int32_t> last(n_bodies, 0), isl_period(plan.n_islands, 1);
-    for (int i = 0; i < m; ++i) {
-      int lv = 0;
-      if (body0[i] >= 0) lv = std::max(lv, last[body0[i]]);
-      if (body1[i] >= 0) lv = std::max(lv, last[body1[i]]);
-      level[i] = lv;
-      if (body0[i] >= 0) { last[body0[i]] = lv + 1; isl_period[cons_island[i]] = std::max(isl_period[cons_island[i]], cnt[body0[i]]); }
-      if (body1[i] >= 0) { last[body1[i]] = lv + 1; isl_period[cons_island[i]] = std::max(isl_period[cons_island[i]], cnt[body1[i]]); }
-    }
     const char *env = std::getenv("EGS_LANE_ORDER");
     const bool by_phase = !(env && std::atoi(env) == 0);
-    for (int i = 0; i < m; ++i) phase[i] = by_phase ? level[i] % isl_period[cons_island[i]] : 0;
+    if (by_phase) {
+      // period of an island = the largest per-body count in it: one pass over the bodies
+      // (a body's island is the island of the first constraint that touched it)
+      std::vector<int32_t> last(n_bodies, 0), isl_period(plan.n_islands, 1), body_island(n_bodies, -1);
+      for (int i = 0; i < m; ++i) {
+        if (body0[i] >= 0 && body_island[body0[i]] < 0) body_island[body0[i]] = cons_island[i];
+        if (body1[i] >= 0 && body_island[body1[i]] < 0) body_island[body1[i]] = cons_island[i];
+      }
+      for (int b = 0; b < n_bodies; ++b)
+        if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], cnt[b]);
+      for (int i = 0; i < m; ++i) {
+        const int b0 = body0[i], b1 = body1[i];
+        int lv = 0;
+        if (b0 >= 0) lv = last[b0];
+        if (b1 >= 0) lv = std::max(lv, last[b1]);
+        if (b0 >= 0) last[b0] = lv + 1;
+        if (b1 >= 0) last[b1] = lv + 1;
+        const int ph = lv % isl_period[cons_island[i]];
+        phase[i] = ph;
+        max_phase = std::max(max_phase, ph);
+      }
+    }
   }
-  // order by (phase, island, list index): two stable counting passes (LSD radix)
+  // order by (phase, island, list index): stable counting sort -- one pass on the combined
+  // key when that needs few buckets, else two passes (LSD radix)
   std::vector<int32_t> order(m);
   {
-    std::vector<int32_t> tmp(m), head;
-    auto counting_pass = [&](const std::vector<int32_t> &key, int n_keys, const int32_t *src, int32_t *dst) {
-      head.assign((size_t)n_keys + 1, 0);
-      for (int k = 0; k < m; ++k) ++head[key[src[k]] + 1];
-      for (int k = 0; k < n_keys; ++k) head[k + 1] += head[k];
-      for (int k = 0; k < m; ++k) dst[head[key[src[k]]]++] = src[k];
-    };
-    std::iota(order.begin(), order.end(), 0);
-    int max_phase = 0;
-    for (int i = 0; i < m; ++i) max_phase = std::max(max_phase, phase[i]);
-    counting_pass(cons_island, plan.n_islands, order.data(), tmp.data());
-    counting_pass(phase, max_phase + 1, tmp.data(), order.data());
+    std::vector<int32_t> head;
+    const long combined = (long)(max_phase + 1) * plan.n_islands;
+    if (combined <= 4L * m + 1024) {
+      head.assign((size_t)combined + 1, 0);
+      for (int i = 0; i < m; ++i) ++head[(size_t)phase[i] * plan.n_islands + cons_island[i] + 1];
+      for (long k = 0; k < combined; ++k) head[k + 1] += head[k];
+      for (int i = 0; i < m; ++i) order[head[(size_t)phase[i] * plan.n_islands + cons_island[i]]++] = i;
+    } else {
+      std::vector<int32_t> tmp(m);
+      auto counting_pass = [&](const std::vector<int32_t> &key, int n_keys, const int32_t *src, int32_t *dst) {
+        head.assign((size_t)n_keys + 1, 0);
+        for (int k = 0; k < m; ++k) ++head[key[src[k]] + 1];
+        for (int k = 0; k < n_keys; ++k) head[k + 1] += head[k];
+        for (int k = 0; k < m; ++k) dst[head[key[src[k]]]++] = src[k];
+      };
+      std::iota(order.begin(), order.end(), 0);
+      counting_pass(cons_island, plan.n_islands, order.data(), tmp.data());
+      counting_pass(phase, max_phase + 1, tmp.data(), order.data());
+    }
   }
 
   LaneDesc idle{};
