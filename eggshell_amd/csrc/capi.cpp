@@ -72,7 +72,7 @@ namespace {
 
 constexpr size_t kEventPairs = 4096;
 constexpr uint32_t kSpinLimit = 1u << 22;
-constexpr int kQuadMaxConstraints = 49152;   // measured crossover: 3 C3 piles on the 4-lane schedule, 4 on the 1-lane one
+constexpr int kQuadMaxConstraints = 65536;   // measured crossover: 4 C3 piles on the 4-lane schedule, 6 on the 1-lane one
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
 // Patches wait on each other, so all of a launch's patches must be co-resident:
 // one 1024-thread workgroup (4 lanes per constraint) or two 256-thread workgroups

@@ -302,10 +302,10 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             ha[0] = an_hist[0]; ha[1] = an_hist[1]; ha[2] = an_hist[2];
           }
         }
-        // 1024-thread tiles: 16 wavefronts share one LDS; the idle ones sleep (see kernels.hip).
-        // Measured: +6 % on a moving C3 pile; slower on body patches (waits on global tickets
-        // cannot be woken), so not there.
-        if (QT >= 256 && !PATCH) asm volatile("s_wakeup");
+        // Waiting wavefronts sleep and are woken by the next ticket store of their workgroup
+        // (see kernels.hip): -5 % on a single C3 pile, -15 % with four piles per launch; slower
+        // on body patches (waits on global tickets cannot be woken), so not there.
+        if (!PATCH) asm volatile("s_wakeup");
         want += cnt;
         spins = 0;
         alive = ++sweep <= A.sweeps;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         ok = false;
         alive = false;
       }
-      if (QT >= 256 && !PATCH && !__any(rdy)) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
+      if (!PATCH && !__any(rdy)) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
