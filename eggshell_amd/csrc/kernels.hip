@@ -448,8 +448,12 @@ __device__ __forceinline__ double dot6p(const double *a, const double *b) {
 
 template <typename REAL>
 __global__ void __launch_bounds__(256) assemble_kernel(const AssembleArgs A) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= A.m) return;
+  // J blocks leave through LDS: a lane's 18 values are 144 B apart from its neighbour's, so direct
+  // stores hit 64 lines per instruction; staged, the workgroup writes its 256 x 18 block contiguously
+  __shared__ REAL stage[256 * 19];   // row stride 19: conflict-free column walks
+  const int i_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i_raw < A.m;
+  const int i = live ? i_raw : A.m - 1;   // the tail lanes recompute the last constraint and store nothing
   const int b0 = A.body0[i], b1 = A.body1[i];
   double d[7];
 #pragma unroll
@@ -545,8 +549,20 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleArgs A) {
   REAL *J0o = reinterpret_cast<REAL *>(A.J0), *J1o = reinterpret_cast<REAL *>(A.J1);
   REAL *loo = reinterpret_cast<REAL *>(A.lo), *hio = reinterpret_cast<REAL *>(A.hi);
   REAL *rhso = reinterpret_cast<REAL *>(A.rhs);
+  {
+    const int first = blockIdx.x * 256;
+    const int count = (A.m - first) < 256 ? (A.m - first) : 256;
 #pragma unroll
-  for (int k = 0; k < 18; ++k) { J0o[(size_t)i * 18 + k] = (REAL)j0[k]; J1o[(size_t)i * 18 + k] = (REAL)j1[k]; }
+    for (int k = 0; k < 18; ++k) stage[threadIdx.x * 19 + k] = (REAL)j0[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < count * 18; e += 256) J0o[(size_t)first * 18 + e] = stage[(e / 18) * 19 + e % 18];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 18; ++k) stage[threadIdx.x * 19 + k] = (REAL)j1[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < count * 18; e += 256) J1o[(size_t)first * 18 + e] = stage[(e / 18) * 19 + e % 18];
+  }
+  if (!live) return;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const double ju = dot6p(j0 + 6 * r, u0) + dot6p(j1 + 6 * r, u1);
@@ -593,17 +609,24 @@ __global__ void __launch_bounds__(256) global_prepare_kernel(const GlobalArgs<RE
 // B = W J^T, D, 1/den for every constraint, indexed by list position (quad path).
 template <typename REAL>
 __global__ void __launch_bounds__(256) cons_prepare_kernel(const SolveArgs<REAL> A) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= A.m) return;
+  __shared__ REAL stage[256 * 19];   // the outputs leave through LDS, contiguously (see assemble_kernel)
+  const int i_raw = blockIdx.x * 256 + threadIdx.x;
+  const int i = i_raw < A.m ? i_raw : A.m - 1;
+  const int first = blockIdx.x * 256;
+  const int count = (A.m - first) < 256 ? (A.m - first) : 256;
   const int b0 = A.body0[i], b1 = A.body1[i];
   Cons<REAL> c;
   load_cons(A, i, b0 >= 0, b1 >= 0, b0, b1, c);
-#pragma unroll
-  for (int k = 0; k < 18; ++k) { A.wsB0[(size_t)i * 18 + k] = c.B0[k]; A.wsB1[(size_t)i * 18 + k] = c.B1[k]; }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) A.wsD[(size_t)i * 9 + k] = c.D[k];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) A.wsInv[(size_t)i * 3 + r] = c.inv[r];
+  auto flush = [&](const REAL *vals, int per, REAL *out) {
+    for (int k = 0; k < per; ++k) stage[threadIdx.x * 19 + k] = vals[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < count * per; e += 256) out[(size_t)first * per + e] = stage[(e / per) * 19 + e % per];
+    __syncthreads();
+  };
+  flush(c.B0, 18, A.wsB0);
+  flush(c.B1, 18, A.wsB1);
+  flush(c.D, 9, A.wsD);
+  flush(c.inv, 3, A.wsInv);
 }
 
 template <typename REAL>
