@@ -178,6 +178,8 @@ struct egs_problem {
   // topology + state (fp64)
   DevBuf<int32_t> body0, body1, kind;
   DevBuf<double> pos, R, v, w, Minv_d, f_ext, data, err, v6, res_partials;
+  DevBuf<double> Wf;            // M^-1 f_ext per body, rebuilt when either is re-uploaded
+  bool wf_valid = false;
   // solver arrays, REAL = double or float (byte buffers)
   DevBuf<unsigned char> Minv_r, J0, J1, lo, hi, rhs, x, acc, wres;
   DevBuf<unsigned char> gB0, gB1, gD, gden, gdx;  // cross-workgroup workspace
@@ -604,11 +606,19 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   return EGS_OK;
 }
 
+void ensure_wf(egs_problem *p) {
+  if (p->wf_valid) return;
+  p->Wf.alloc((size_t)(p->n > 0 ? p->n : 1) * 6);
+  launch_mass_times_force(p->n, p->Minv_d.p, p->f_ext.p, p->Wf.p, p->ctx->stream);
+  p->wf_valid = true;
+}
+
 void do_assemble(egs_problem *p, double dt, double erp) {
   AssembleArgs a;
   a.n = p->n; a.m = p->m;
   a.pos = p->pos.p; a.R = p->R.p; a.v = p->v.p; a.w = p->w.p;
-  a.Minv = p->Minv_d.p; a.f_ext = p->f_ext.p;
+  ensure_wf(p);
+  a.Wf = p->Wf.p;
   a.kind = p->kind.p; a.body0 = p->body0.p; a.body1 = p->body1.p;
   a.data = p->data.p;
   a.dt = dt; a.erp = erp;
@@ -621,10 +631,11 @@ void do_assemble(egs_problem *p, double dt, double erp) {
 }
 
 void do_velocity(egs_problem *p, double dt) {
+  ensure_wf(p);
   if (p->precision == EGS_F32)
-    launch_velocity<float>(p->n, p->v.p, p->w.p, p->Minv_d.p, p->f_ext.p, reinterpret_cast<const float *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
+    launch_velocity<float>(p->n, p->v.p, p->w.p, p->Wf.p, reinterpret_cast<const float *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
   else
-    launch_velocity<double>(p->n, p->v.p, p->w.p, p->Minv_d.p, p->f_ext.p, reinterpret_cast<const double *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
+    launch_velocity<double>(p->n, p->v.p, p->w.p, p->Wf.p, reinterpret_cast<const double *>(p->acc.p), dt, p->v6.p, p->ctx->stream);
   HIPCHK(hipGetLastError());
 }
 
@@ -919,7 +930,7 @@ egs_status egs_problem_set_blocks(egs_problem *p, const double *Minv, const doub
   if (!p) return EGS_ERR_INVALID;
   return guarded(p->ctx, [&]() -> egs_status {
     const size_t n = p->n, m = p->m;
-    if (Minv && n) { upload(p->Minv_d, Minv, n * 36, p->ctx->stream); p->minv_r_valid = false; }
+    if (Minv && n) { upload(p->Minv_d, Minv, n * 36, p->ctx->stream); p->minv_r_valid = false; p->wf_valid = false; }
     upload_real(p, p->J0, J0, m * 18);
     upload_real(p, p->J1, J1, m * 18);
     if (is_eq && m) upload(p->is_eq, is_eq, m * 3, p->ctx->stream);
@@ -956,8 +967,8 @@ egs_status egs_problem_set_state(egs_problem *p, const double *pos, const double
     if (R) upload(p->R, R, n * 9, s);
     if (v) upload(p->v, v, n * 3, s);
     if (w) upload(p->w, w, n * 3, s);
-    if (Minv) { upload(p->Minv_d, Minv, n * 36, s); p->minv_r_valid = false; }
-    if (f_ext) upload(p->f_ext, f_ext, n * 6, s);
+    if (Minv) { upload(p->Minv_d, Minv, n * 36, s); p->minv_r_valid = false; p->wf_valid = false; }
+    if (f_ext) { upload(p->f_ext, f_ext, n * 6, s); p->wf_valid = false; }
     p->have_state = true;
     return EGS_OK;
   });
@@ -975,7 +986,7 @@ egs_status egs_problem_set_mass(egs_problem *p, const double *inv_mass, const do
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) W[6 * (3 + r) + 3 + c] = inv_inertia[b * 9 + 3 * r + c];
     }
-    if (n) { upload(p->Minv_d, blocks.data(), n * 36, p->ctx->stream); p->minv_r_valid = false; }
+    if (n) { upload(p->Minv_d, blocks.data(), n * 36, p->ctx->stream); p->minv_r_valid = false; p->wf_valid = false; }
     return EGS_OK;
   });
 }

@@ -62,7 +62,8 @@ struct GlobalArgs {
 
 struct AssembleArgs {
   int32_t n, m;
-  const double *pos, *R, *v, *w, *Minv, *f_ext;  // body state, fp64
+  const double *pos, *R, *v, *w;                 // body state, fp64
+  const double *Wf;                              // [n][6] M^-1 f_ext (launch_mass_times_force)
   const int32_t *kind, *body0, *body1;
   const double *data;                            // [m][7]
   double dt, erp;
@@ -71,6 +72,9 @@ struct AssembleArgs {
   uint8_t *is_eq;
 };
 
+// Wf[b] = M_b^-1 f_ext,b: both frozen at Init (Q5), so assembly and the velocity update read
+// these 48 B per body instead of the 288 B block and the force (same expression, same bits).
+void launch_mass_times_force(int n, const double *Minv, const double *f_ext, double *Wf, hipStream_t s);
 template <typename REAL>
 void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
@@ -99,8 +103,7 @@ void launch_residual_partials(int rows, const REAL *wres, const REAL *x,
                               const uint8_t *is_eq, double *out, int blocks,
                               hipStream_t s);
 template <typename REAL>
-void launch_velocity(int n, const double *v, const double *w,
-                     const double *Minv, const double *f_ext, const REAL *acc,
+void launch_velocity(int n, const double *v, const double *w, const double *Wf, const REAL *acc,
                      double dt, double *v6, hipStream_t s);
 // Residual partial sums (the 4 categories of sparse_iterations.cc:51-69, `blocks` partial
 // sums each, same reduction order as launch_residual_partials) for every sweep of a recorded

@@ -301,20 +301,23 @@ __global__ void __launch_bounds__(256) hist_residual_kernel(const SolveArgs<REAL
 // --------------------------------------------------------------------------
 // K9: v_new = v + dt (W f_ext + a)        (ensembles.cc:535, 572)
 template <typename REAL>
-__global__ void __launch_bounds__(256) velocity_kernel(int n, const double *v, const double *w, const double *Minv,
-                                                       const double *f_ext, const REAL *acc, double dt, double *v6) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= n) return;
-  double f[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) f[k] = f_ext[(size_t)b * 6 + k];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const double *M = Minv + (size_t)b * 36 + 6 * r;
-    double wf = ((((M[0] * f[0] + M[1] * f[1]) + M[2] * f[2]) + M[3] * f[3]) + M[4] * f[4]) + M[5] * f[5];
-    double vel = r < 3 ? v[(size_t)b * 3 + r] : w[(size_t)b * 3 + r - 3];
-    v6[(size_t)b * 6 + r] = vel + dt * (wf + (double)acc[(size_t)b * 6 + r]);
-  }
+__global__ void __launch_bounds__(256) velocity_kernel(int n, const double *v, const double *w, const double *Wf,
+                                                       const REAL *acc, double dt, double *v6) {
+  const int e = blockIdx.x * 256 + threadIdx.x;   // one lane per (body, component): every access contiguous
+  if (e >= 6 * n) return;
+  const int b = e / 6, r = e - 6 * b;
+  const double vel = r < 3 ? v[(size_t)b * 3 + r] : w[(size_t)b * 3 + r - 3];
+  v6[e] = vel + dt * (Wf[e] + (double)acc[e]);
+}
+
+// Wf = M^-1 f_ext per body, the expression of ComputeVDot's M_inverse_ * external_force_torque_
+// restricted to the diagonal block (ensembles.cc:535)
+__global__ void __launch_bounds__(256) mass_times_force_kernel(int n, const double *Minv, const double *f_ext, double *Wf) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 6 * n) return;
+  const int b = e / 6, r = e - 6 * b;
+  const double *M = Minv + (size_t)b * 36 + 6 * r, *f = f_ext + (size_t)b * 6;
+  Wf[e] = ((((M[0] * f[0] + M[1] * f[1]) + M[2] * f[2]) + M[3] * f[3]) + M[4] * f[4]) + M[5] * f[5];
 }
 
 // StepPositions_ODE (ensembles.cc:577-591): p += dt (v + v_new)/2,
@@ -535,14 +538,14 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleArgs A) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const double vel = r < 3 ? A.v[(size_t)b0 * 3 + r] : A.w[(size_t)b0 * 3 + r - 3];
-      u0[r] = vel / A.dt + dot6p(A.Minv + (size_t)b0 * 36 + 6 * r, A.f_ext + (size_t)b0 * 6);
+      u0[r] = vel / A.dt + A.Wf[(size_t)b0 * 6 + r];
     }
   }
   if (b1 >= 0) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const double vel = r < 3 ? A.v[(size_t)b1 * 3 + r] : A.w[(size_t)b1 * 3 + r - 3];
-      u1[r] = vel / A.dt + dot6p(A.Minv + (size_t)b1 * 36 + 6 * r, A.f_ext + (size_t)b1 * 6);
+      u1[r] = vel / A.dt + A.Wf[(size_t)b1 * 6 + r];
     }
   }
   const double kk = -A.erp / A.dt / A.dt;
@@ -830,10 +833,15 @@ void launch_hist_residual(const SolveArgs<REAL> &a, int sweeps, int blocks, doub
 }
 
 template <typename REAL>
-void launch_velocity(int n, const double *v, const double *w, const double *Minv, const double *f_ext,
-                     const REAL *acc, double dt, double *v6, hipStream_t s) {
+void launch_velocity(int n, const double *v, const double *w, const double *Wf, const REAL *acc, double dt, double *v6,
+                     hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL((velocity_kernel<REAL>), dim3((n + 255) / 256), dim3(256), 0, s, n, v, w, Minv, f_ext, acc, dt, v6);
+  hipLaunchKernelGGL((velocity_kernel<REAL>), dim3((6 * n + 255) / 256), dim3(256), 0, s, n, v, w, Wf, acc, dt, v6);
+}
+
+void launch_mass_times_force(int n, const double *Minv, const double *f_ext, double *Wf, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(mass_times_force_kernel, dim3((6 * n + 255) / 256), dim3(256), 0, s, n, Minv, f_ext, Wf);
 }
 
 void launch_advance(int n, double *pos, double *R, double *v, double *w, const double *v6, double dt, hipStream_t s) {
@@ -904,8 +912,8 @@ void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s) {
   template void launch_assemble<REAL>(const AssembleArgs &, hipStream_t);                                    \
   template void launch_residual_partials<REAL>(int, const REAL *, const REAL *, const REAL *, const REAL *,  \
                                                const uint8_t *, double *, int, hipStream_t);                 \
-  template void launch_velocity<REAL>(int, const double *, const double *, const double *, const double *,   \
-                                      const REAL *, double, double *, hipStream_t);                          \
+  template void launch_velocity<REAL>(int, const double *, const double *, const double *, const REAL *, double,   \
+                                      double *, hipStream_t);                          \
   template void launch_convert_minv<REAL>(int, const double *, REAL *, hipStream_t);                         \
   template void launch_minv_iso<REAL>(int, const REAL *, int *, hipStream_t);                               \
   template void launch_hist_residual<REAL>(const SolveArgs<REAL> &, int, int, double *, int, hipStream_t);
