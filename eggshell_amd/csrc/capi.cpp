@@ -790,7 +790,7 @@ void ensure_tile_plan(egs_problem *p) {
 
 // (Re)build everything that depends on the constraint topology.  Body state
 // (pos, R, v, w, M^-1, f_ext) is kept when n is unchanged; buffers only grow.
-void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const int32_t *body1) {
+void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const int32_t *body1, bool fresh = true) {
   egs_context *ctx = p->ctx;
   const int n = p->n;
   hipStream_t s = ctx->stream;
@@ -835,8 +835,10 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   p->x.alloc(mm * 3 * rs); p->wres.alloc(mm * 3 * rs);
   p->is_eq.alloc(mm * 3);
   HIPCHK(hipMemsetAsync(p->acc.p, 0, nn * 6 * rs, s));
-  HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
-  HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
+  if (fresh) {   // a re-planned world overwrites both in its next solve; a new problem reads as zeros
+    HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
+    HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
+  }
   HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
   HIPCHK(hipStreamSynchronize(s));
   // the 1-lane schedule is built at the first solve that needs it (ensure_tile_plan):
@@ -1248,7 +1250,7 @@ void world_make_problem(egs_world *w, const int32_t *b0, const int32_t *b1, int 
   } else {  // same bodies, new constraint list: the body state stays where it is
     if (check_topology(w->ctx, w->n, m, b0, b1) != EGS_OK)
       throw std::invalid_argument(egs_last_error(w->ctx));
-    problem_set_topology(w->prob, m, b0, b1);
+    problem_set_topology(w->prob, m, b0, b1, /*fresh=*/false);
   }
   egs_problem *np = w->prob;
   // constraint kinds: joints first, then contacts; joint descriptors are static
@@ -1256,7 +1258,8 @@ void world_make_problem(egs_world *w, const int32_t *b0, const int32_t *b1, int 
   const int mj = (int)w->jb0.size();
   for (int i = 0; i < mj; ++i) kind[i] = EGS_JOINT_BALL;
   if (m > 0) {
-    upload(np->kind, kind.data(), (size_t)m, s);
+    kind.resize((size_t)m);
+    stage(w->ctx, np->kind, kind);   // through the pinned arena (reset only after a synchronise): no wait here
     if (mj > 0) upload(np->data, w->jdata.data(), (size_t)mj * 7, s);
   }
   np->have_constraints = true;
