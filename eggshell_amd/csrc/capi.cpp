@@ -811,7 +811,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
       const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
-      p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock);
+      p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq);
       if (p->planq.global.empty()) {
         const Plan &pq = p->planq;
         p->use_quad = true;

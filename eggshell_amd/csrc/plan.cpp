@@ -127,10 +127,18 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
 }  // namespace
 
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
-                int block) {
+                int block, Plan *recycle) {
   if (n_bodies < 0 || m < 0 || block < 0 || block > 1024)
     throw std::invalid_argument("build_plan: bad sizes");
   Plan plan;
+  if (recycle) {   // keep the storage, drop the contents
+    plan = std::move(*recycle);
+    plan.n_islands = plan.n_tiles = 0; plan.max_slots = 1; plan.max_cnt = 1;
+    plan.lanes.clear(); plan.tile_nslots.clear(); plan.tile_slot_off.clear(); plan.slot_body.clear();
+    plan.global.clear();
+    plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0;
+    plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear(); plan.patch_slot_body.clear();
+  }
   plan.n = n_bodies; plan.m = m; plan.block = block;
   for (int i = 0; i < m; ++i) {
     if (body0[i] < -1 || body0[i] >= n_bodies || body1[i] < -1 || body1[i] >= n_bodies)
