@@ -178,11 +178,21 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qr = r0 + (wave >> 1) * 32, qc = c0 + (wave & 1) * 32;
   const int li = lane & 15, lk = lane >> 4;
-  double4_t acc[2][2];
+  double4_t acc[2][2], told[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // the tile's old values, requested before the operands: the final T -= acc costs no second round trip
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
+        told[ti][tj][reg] = (r < nrows && c < ld && c <= r) ? T[(size_t)r * ld + c] : 0.0;
+      }
   const double *Pa[2], *Pb[2];
   bool va[2], vb[2];
 #pragma unroll
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
-        if (r < nrows && c < ld && c <= r) T[(size_t)r * ld + c] -= acc[ti][tj][reg];
+        if (r < nrows && c < ld && c <= r) T[(size_t)r * ld + c] = told[ti][tj][reg] - acc[ti][tj][reg];
       }
 }
 
@@ -231,13 +241,25 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
   const int tid = threadIdx.x;
   for (int i = tid; i < nf; i += 1024) xs[i] = T[(size_t)yrow * ld + i];
   __syncthreads();
+  // thread (i, part) of the 64 x 16 layout multiplies rows part, part+16, ... of the inverse block;
+  // its four entries for the NEXT block are requested before this block's strip update
+  const int i = tid & 63, part = tid >> 6;
+  double li[4];
+  {
+    const double *Li = inv + (size_t)((nf - NB) / NB) * NB * NB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) li[q] = nf >= NB ? Li[(part + 16 * q) * NB + i] : 0.0;
+  }
   for (int kb = nf - NB; kb >= 0; kb -= NB) {
-    const double *Li = inv + (size_t)(kb / NB) * NB * NB;
-    const int i = tid & 63, part = tid >> 6;
     double s = 0.0;
 #pragma unroll
-    for (int r = part; r < NB; r += 16) s = __builtin_fma(Li[r * NB + i], xs[kb + r], s);   // Linv[r][i] = 0 for i > r
+    for (int q = 0; q < 4; ++q) s = __builtin_fma(li[q], xs[kb + part + 16 * q], s);   // Linv[r][i] = 0 for i > r
     red[part][i] = s;
+    if (kb >= NB) {
+      const double *Ln = inv + (size_t)(kb / NB - 1) * NB * NB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) li[q] = Ln[(part + 16 * q) * NB + i];
+    }
     __syncthreads();
     if (tid < NB) {
       double x = 0.0;
