@@ -283,21 +283,32 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
 // max |a_ij| and max |a_ij - a_ji| over i > j (non-negative doubles order like
 // their bit patterns, so an integer atomicMax does the reduction).
 __global__ void __launch_bounds__(256) symmetry_kernel(const double *A, int N, unsigned long long *out /*[2]*/) {
+  // 32 x 32 tiles: tile (bi, bj) with bj <= bi is compared with the transpose of tile (bj, bi)
+  // staged through LDS, so both reads walk rows
+  __shared__ double tT[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
   double amax = 0.0, asym = 0.0;
-  const size_t total = (size_t)N * N;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int i = (int)(idx / N), j = (int)(idx % N);
-    if (j < i) {
-      const double v = A[idx];
-      amax = fmax(amax, fabs(v));
-      asym = fmax(asym, fabs(v - A[(size_t)j * N + i]));
+  if (bj <= bi) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+      const int gi = bj * 32 + r, gj = bi * 32 + tx;           // element of the mirror tile
+      tT[r][tx] = (gi < N && gj < N) ? A[(size_t)gi * N + gj] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int gi = bi * 32 + r, gj = bj * 32 + tx;
+      if (gi < N && gj < N && gj < gi) {
+        const double v = A[(size_t)gi * N + gj];
+        amax = fmax(amax, fabs(v));
+        asym = fmax(asym, fabs(v - tT[tx][r]));
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
     amax = fmax(amax, __shfl_down(amax, o, 64));
     asym = fmax(asym, __shfl_down(asym, o, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0 && (amax > 0.0 || asym > 0.0)) {
     atomicMax(&out[0], (unsigned long long)__double_as_longlong(amax));
     atomicMax(&out[1], (unsigned long long)__double_as_longlong(asym));
   }
@@ -861,7 +872,7 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
     Buf<unsigned long long> sym_d(2);
     unsigned long long sym_h[2] = {0, 0};
     HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(symmetry_kernel, dim3(grid1((size_t)N * N)), dim3(256), 0, s, dA.p, N, sym_d.p);
+    hipLaunchKernelGGL(symmetry_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, s, dA.p, N, sym_d.p);
     HIPCHK(hipMemcpyAsync(sym_h, sym_d.p, sizeof sym_h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     double amax, asym;

@@ -140,3 +140,22 @@ def test_single_workgroup_loop_reports_indefinite_matrix(ctx):
     A = np.array([[1.0, 2.0], [2.0, 1.0]])       # symmetric, eigenvalues 3 and -1
     ok, x, w, piv = ctx.mixed_constraints_solve(A, np.array([1.0, 1.0]), np.zeros(2, np.uint8), np.zeros(2), np.full(2, INF))
     assert not ok
+
+
+@pytest.mark.parametrize("dim", [5, 70, 300])
+def test_asymmetric_matrix_is_rejected(ctx, dim):
+    """The factorisations read the lower triangle only, so A must be symmetric: a single
+    perturbed entry anywhere (tile interior, tile edge, last row) is reported as
+    EGS_ERR_INVALID, a symmetric matrix of the same size is accepted."""
+    from eggshell_amd import capi
+    rng = np.random.default_rng(dim)
+    A = _spd(rng, dim) + 0.2 * np.eye(dim)
+    b = rng.uniform(-1, 1, dim)
+    args = (b, np.zeros(dim, np.uint8), np.zeros(dim), np.full(dim, INF))
+    assert ctx.mixed_constraints_solve(A, *args)[0]
+    for (i, j) in ((1, 0), (dim - 1, dim // 2), (dim // 2, dim // 3)):
+        Abad = A.copy()
+        Abad[i, j] += 1e-3
+        with pytest.raises(capi.EgsError) as e:
+            ctx.mixed_constraints_solve(Abad, *args)
+        assert e.value.status == capi.ERR_INVALID
