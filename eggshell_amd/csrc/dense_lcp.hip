@@ -308,9 +308,12 @@ __global__ void __launch_bounds__(256) symmetry_kernel(const double *A, int N, u
     amax = fmax(amax, __shfl_down(amax, o, 64));
     asym = fmax(asym, __shfl_down(asym, o, 64));
   }
-  if ((threadIdx.x & 63) == 0 && (amax > 0.0 || asym > 0.0)) {
-    atomicMax(&out[0], (unsigned long long)__double_as_longlong(amax));
-    atomicMax(&out[1], (unsigned long long)__double_as_longlong(asym));
+  if ((threadIdx.x & 63) == 0) {
+    // the maxima only grow: a (possibly stale) plain read that is already >= ours makes the atomic
+    // pointless -- almost every wavefront then skips it instead of queueing on two addresses
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(amax), us = (unsigned long long)__double_as_longlong(asym);
+    if (ua > __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out[0], ua);
+    if (us > __hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out[1], us);
   }
 }
 
@@ -370,14 +373,28 @@ __global__ void __launch_bounds__(256) gemv_minus_kernel(const double *M, int n,
   if (lane == 0) out[row] = s - sub[row];
 }
 
-// t_k = T[last][k] - sum_j T[nepad+j][k] xi[j]   (k < nepad), in place.
-__global__ void __launch_bounds__(256) xe_rhs_kernel(double *T, int nepad, int ni, const double *xi) {
+// t_k = T[last][k] - sum_j T[nepad+j][k] xi[j]   (k < nepad), in place.  One workgroup per 64
+// columns; 16 row groups each sum every 16th row (row reads stay contiguous), then one LDS pass.
+__global__ void __launch_bounds__(1024) xe_rhs_kernel(double *T, int nepad, int ni, const double *xi) {
+  __shared__ double red[16][64];
   const int ld = nepad + ni;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nepad) return;
-  double s = T[(size_t)(nepad + ni) * ld + k];
-  for (int j = 0; j < ni; ++j) s = __builtin_fma(-T[(size_t)(nepad + j) * ld + k], xi[j], s);
-  T[(size_t)(nepad + ni) * ld + k] = s;
+  const int kk = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kk;          // nepad is a multiple of 64
+  double s0 = 0.0, s1 = 0.0;
+  int j = part;
+  for (; j + 16 < ni; j += 32) {
+    s0 = __builtin_fma(T[(size_t)(nepad + j) * ld + k], xi[j], s0);
+    s1 = __builtin_fma(T[(size_t)(nepad + j + 16) * ld + k], xi[j + 16], s1);
+  }
+  for (; j < ni; j += 16) s0 = __builtin_fma(T[(size_t)(nepad + j) * ld + k], xi[j], s0);
+  red[part][kk] = s0 + s1;
+  __syncthreads();
+  if (part == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) sum += red[p][kk];
+    T[(size_t)(nepad + ni) * ld + k] -= sum;
+  }
 }
 
 // ---- Murty bookkeeping -------------------------------------------------------
@@ -898,7 +915,7 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)
   std::vector<double> xih(ni), wih(ni), xeh(ne);
   if (ne) {
-    hipLaunchKernelGGL(xe_rhs_kernel, dim3((nepad + 255) / 256), dim3(256), 0, s, T.p, nepad, ni, xi.p);
+    hipLaunchKernelGGL(xe_rhs_kernel, dim3(nepad / NB), dim3(1024), 0, s, T.p, nepad, ni, xi.p);
     hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p,
                        dinv.p);
     HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
