@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(BLOCK, ISO ? (sizeof(REAL) == 4 ? 4 : 3) : 1) 
           hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
         }
         for (int q = tid + 1; q < nslots; q += BLOCK) {
+          if (slot_body[q] < 0) continue;   // slot numbers have gaps (plan.cpp, bank-aware numbering)
           REAL *ha = A.hist_acc + ((size_t)(s - 1) * A.n_bodies + slot_body[q]) * 6;
 #pragma unroll
           for (int k = 0; k < 6; ++k) ha[k] = s_acc[q * 6 + k];
@@ -220,6 +221,7 @@ __global__ void __launch_bounds__(BLOCK, ISO ? (sizeof(REAL) == 4 ? 4 : 3) : 1) 
   }
   for (int s = tid + 1; s < nslots; s += BLOCK) {
     const int body = slot_body[s];
+    if (body < 0) continue;   // unused slot number
 #pragma unroll
     for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
   }

@@ -2,6 +2,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
@@ -172,7 +173,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     ++island_size[isl];
   }
   plan.n_islands = (int)island_size.size();
-  if (block == kAutoQuadBlock) {
+  const bool quad_plan = block == kAutoQuadBlock;
+  if (quad_plan) {
     int largest = 0;
     for (int sz : island_size) largest = std::max(largest, sz);
     block = largest <= 64 ? 64 : (largest <= 128 ? 128 : 256);
@@ -274,28 +276,144 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   std::vector<int32_t> lane_fill(plan.n_tiles, 0);
   std::vector<int32_t> body_slot(n_bodies, -1), body_tile(n_bodies, -1);
 
-  auto slot_of = [&](int tile, int body) -> uint16_t {
-    if (body < 0) return 0;
-    if (body_slot[body] < 0) {
-      body_slot[body] = plan.tile_nslots[tile]++;
-      body_tile[body] = tile;
-    }
-    return (uint16_t)body_slot[body];
-  };
-
+  // (bank-aware slot numbering, below) body -> where its uses sit inside its tile, CSR over the
+  // bodies in rank order; a use = (half-wave << 2 | b128 pass of the half-wave << 1 | side)
+  static const bool bank_aware = [] { const char *e = std::getenv("EGS_SLOT_BANKS"); return !(e && std::atoi(e) == 0); }();
+  const bool colour = bank_aware && !quad_plan;
+  std::vector<int32_t> use_off, use_lane;
+  if (colour) {
+    use_off.resize((size_t)n_bodies + 1);
+    use_off[0] = 0;
+    for (int b = 0; b < n_bodies; ++b) use_off[b + 1] = use_off[b] + cnt[b];
+    use_lane.resize((size_t)use_off[n_bodies] + 1);
+  }
   for (int k = 0; k < m; ++k) {
     const int i = order[k];
     const int tile = island_tile[cons_island[i]];
     if (tile == -2) continue;
+    const int b0 = body0[i], b1 = body1[i], l = lane_fill[tile]++;
     LaneDesc d;
     d.cidx = i;
-    d.slot0 = slot_of(tile, body0[i]);
-    d.slot1 = slot_of(tile, body1[i]);
+    d.slot0 = d.slot1 = 0;
     d.pos0 = (uint16_t)pos0[i];
-    d.cnt0 = (uint16_t)(body0[i] >= 0 ? cnt[body0[i]] : 0);
+    d.cnt0 = (uint16_t)(b0 >= 0 ? cnt[b0] : 0);
     d.pos1 = (uint16_t)pos1[i];
-    d.cnt1 = (uint16_t)(body1[i] >= 0 ? cnt[body1[i]] : 0);
-    plan.lanes[(size_t)tile * block + lane_fill[tile]++] = d;
+    d.cnt1 = (uint16_t)(b1 >= 0 ? cnt[b1] : 0);
+    plan.lanes[(size_t)tile * block + l] = d;
+    if (colour) {
+      const int li = l & 31;
+      const int where = (l >> 5) << 2 | ((li < 4 || (li >= 12 && li < 16) || (li >= 20 && li < 28)) ? 0 : 2);
+      if (b0 >= 0) use_lane[use_off[b0] + pos0[i]] = where;
+      if (b1 >= 0 && b1 != b0) use_lane[use_off[b1] + pos1[i]] = where | 1;
+    }
+  }
+  // LDS slots.  A slot's number decides its banks: the ticket word s_tick[slot] is polled with
+  // ds_read_b32 (bank = slot mod 32, the 32 lanes of a half-wave share a pass) and the 48-byte
+  // accumulator is read as three ds_read_b128 (16-byte piece 3*slot+k mod 16, passes of 16 lanes:
+  // {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half-wave; 3 is invertible mod 16, so pieces
+  // collide exactly when slots are equal mod 16).  Two lanes of a pass that hit one bank with
+  // DIFFERENT slots cost an extra LDS cycle each, inside the poll loop the sweep's critical path
+  // runs through.  So a tile's bodies, in first-use order, each take the free slot whose residue
+  // mod 32 is used least by other bodies in the passes its lanes sit in (side 0 and side 1 are
+  // separate instructions, hence separate masks).  Quad plans (4 lanes per constraint, nearly no
+  // conflicts measured) keep first-use numbering.  (Rocprof, C3 x 24: 35 % of the tile kernel's
+  // LDS cycles were bank conflicts with first-use numbering.)
+  {
+    std::vector<uint32_t> half_mask, pass_mask;     // [pass][side]: residues in use
+    std::vector<int32_t> next_free(32);
+    for (int t = 0; t < plan.n_tiles; ++t) {
+      LaneDesc *L = plan.lanes.data() + (size_t)t * block;
+      const int nl = lane_fill[t];
+      if (!colour) {
+        for (int l = 0; l < nl; ++l)
+          for (int side = 0; side < 2; ++side) {
+            const int body = side ? body1[L[l].cidx] : body0[L[l].cidx];
+            if (body >= 0 && body_slot[body] < 0) { body_slot[body] = plan.tile_nslots[t]++; body_tile[body] = t; }
+          }
+      } else {
+        half_mask.assign((size_t)(block / 32 + 1) * 2, 0u);
+        pass_mask.assign((size_t)(block / 32 + 1) * 4, 0u);
+        for (int r = 0; r < 32; ++r) next_free[r] = r ? r : 32;   // slot 0 = the world
+        int top = 0, placed = 0, rr = 1;
+        auto lowest = [&](uint32_t mset) {
+          int best = -1;
+          for (; mset; mset &= mset - 1) {
+            const int r = __builtin_ctz(mset);
+            if (best < 0 || next_free[r] < next_free[best]) best = r;
+          }
+          return best;
+        };
+        auto place = [&](int body) {
+          const int32_t *u0 = use_lane.data() + use_off[body], *u1 = u0 + cnt[body];
+          uint32_t used32 = 0, used16 = 0;
+          for (const int32_t *u = u0; u < u1; ++u) {
+            used32 |= half_mask[(size_t)(*u >> 2) * 2 + (*u & 1)];
+            used16 |= pass_mask[*u];
+          }
+          used16 |= used16 << 16;
+          // free residues, best first: clean for both, clean for the accumulator, clean for the ticket
+          uint32_t pick = ~(used32 | used16);
+          if (!pick) pick = ~used16;
+          if (!pick) pick = ~used32;
+          if (!pick) pick = ~0u;
+          // among them a low free slot keeps the numbering dense: never more than 64 numbers
+          // beyond a dense numbering (LDS is sized by the top slot)
+          // (taken round-robin from the residue after the last one; the exact lowest only when
+          // that drifts too far)
+          const uint32_t rot = (pick >> rr) | (pick << ((32 - rr) & 31));
+          int best = (__builtin_ctz(rot) + rr) & 31;
+          if (next_free[best] > placed + 64) best = lowest(~0u);
+          rr = (best + 1) & 31;
+          ++placed;
+          const int slot = next_free[best];
+          next_free[best] += 32;
+          top = std::max(top, slot);
+          body_slot[body] = slot; body_tile[body] = t;
+          for (const int32_t *u = u0; u < u1; ++u) {
+            half_mask[(size_t)(*u >> 2) * 2 + (*u & 1)] |= 1u << best;
+            pass_mask[*u] |= 1u << (best & 15);
+          }
+        };
+        for (int l = 0; l < nl; ++l) {
+          const int c = L[l].cidx;
+          if (body0[c] >= 0 && body_slot[body0[c]] < 0) place(body0[c]);
+          if (body1[c] >= 0 && body_slot[body1[c]] < 0) place(body1[c]);
+        }
+        plan.tile_nslots[t] = top + 1;
+      }
+      for (int l = 0; l < nl; ++l) {
+        const int c = L[l].cidx;
+        L[l].slot0 = body0[c] >= 0 ? (uint16_t)body_slot[body0[c]] : 0;
+        L[l].slot1 = body1[c] >= 0 ? (uint16_t)body_slot[body1[c]] : 0;
+      }
+    }
+  }
+  if (const char *e = std::getenv("EGS_PLAN_STATS"); e && std::atoi(e) != 0) {
+    // modelled extra LDS cycles with every lane active: distinct slots on one bank within a pass
+    long tick_extra = 0, acc_extra = 0, passes = 0;
+    for (int t = 0; t < plan.n_tiles; ++t) {
+      const LaneDesc *L = plan.lanes.data() + (size_t)t * block;
+      for (int side = 0; side < 2; ++side)
+        for (int h = 0; h < block / 32; ++h) {
+          std::vector<int> seen32[32], seen16[2][16];
+          for (int li = 0; li < 32; ++li) {
+            const LaneDesc &d = L[h * 32 + li];
+            if (d.cidx < 0) continue;
+            const int body = side ? body1[d.cidx] : body0[d.cidx];
+            if (body < 0) continue;
+            const int slot = side ? d.slot1 : d.slot0;
+            const int pass = (li < 4 || (li >= 12 && li < 16) || (li >= 20 && li < 28)) ? 0 : 1;
+            auto add = [&](std::vector<int> &v) { if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot); };
+            add(seen32[slot & 31]); add(seen16[pass][slot & 15]);
+          }
+          int w32 = 1, w16[2] = {1, 1};
+          for (int r = 0; r < 32; ++r) w32 = std::max(w32, (int)seen32[r].size());
+          for (int q = 0; q < 2; ++q) for (int r = 0; r < 16; ++r) w16[q] = std::max(w16[q], (int)seen16[q][r].size());
+          tick_extra += w32 - 1; acc_extra += (w16[0] - 1) + (w16[1] - 1); ++passes;
+        }
+    }
+    std::fprintf(stderr, "[egs plan] tiles %d block %d max_slots(pre) half-wave passes %ld: ticket extra cycles %ld, accumulator extra %ld (x3 pieces)\n",
+                 plan.n_tiles, block, passes, tick_extra, acc_extra);
   }
   int off = 0;
   for (int t = 0; t < plan.n_tiles; ++t) {
