@@ -26,7 +26,7 @@ EXPORTS = [
     "egs_problem_set_state", "egs_problem_set_mass", "egs_problem_set_constraints", "egs_problem_assemble",
     "egs_problem_step", "egs_problem_get_blocks", "egs_problem_get_velocity",
     "egs_problem_advance", "egs_problem_get_state",
-    "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan",
+    "egs_problem_get_stats", "egs_mixed_constraints_solve", "egs_debug_plan", "egs_debug_plan_slots",
     "egs_update_contacts", "egs_update_contacts_joints", "egs_world_create", "egs_world_destroy", "egs_world_set_bodies",
     "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
     "egs_world_get_lambda", "egs_world_info",
@@ -296,6 +296,19 @@ def debug_plan(n_bodies, body0, body1, tile_size=256):
         raise EgsError(st, "egs_debug_plan failed")
     return dict(n_islands=ni.value, n_tiles=nt.value, n_global=ng.value, cons_tile=out[0],
                 pos0=out[1], cnt0=out[2], pos1=out[3], cnt1=out[4])
+
+
+def debug_plan_slots(n_bodies, body0, body1, tile_size=256):
+    """Host-only: per constraint its lane in the tile, the LDS slots of its two sides and
+    the slot count of its tile (see egs_debug_plan_slots)."""
+    body0, body1 = _i32(body0), _i32(body1)
+    m = body0.shape[0]
+    out = [np.zeros(m, np.int32) for _ in range(4)]
+    st = load().egs_debug_plan_slots(C.c_int32(n_bodies), C.c_int32(m), _p(body0), _p(body1), C.c_int32(tile_size),
+                                     *[_p(o) for o in out])
+    if st != OK:
+        raise EgsError(st, "egs_debug_plan_slots failed")
+    return dict(lane=out[0], slot0=out[1], slot1=out[2], tile_nslots=out[3])
 
 
 class World:

@@ -1208,6 +1208,32 @@ egs_status egs_debug_plan(int32_t n, int32_t m, const int32_t *body0, const int3
   }
 }
 
+egs_status egs_debug_plan_slots(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,
+                                int32_t *lane, int32_t *slot0, int32_t *slot1, int32_t *tile_nslots) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
+  try {
+    const Plan pl = build_plan(n, m, body0, body1, tile_size);
+    for (int i = 0; i < m; ++i) {
+      if (lane) lane[i] = -1;
+      if (slot0) slot0[i] = -1;
+      if (slot1) slot1[i] = -1;
+      if (tile_nslots) tile_nslots[i] = -1;
+    }
+    for (int t = 0; t < pl.n_tiles; ++t)
+      for (int l = 0; l < pl.block; ++l) {
+        const LaneDesc &d = pl.lanes[(size_t)t * pl.block + l];
+        if (d.cidx < 0) continue;
+        if (lane) lane[d.cidx] = l;
+        if (slot0) slot0[d.cidx] = d.slot0;
+        if (slot1) slot1[d.cidx] = d.slot1;
+        if (tile_nslots) tile_nslots[d.cidx] = pl.tile_nslots[t];
+      }
+    return EGS_OK;
+  } catch (const std::exception &) {
+    return EGS_ERR_INVALID;
+  }
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------

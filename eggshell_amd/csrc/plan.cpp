@@ -278,8 +278,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
 
   // (bank-aware slot numbering, below) body -> where its uses sit inside its tile, CSR over the
   // bodies in rank order; a use = (half-wave << 2 | b128 pass of the half-wave << 1 | side)
-  static const bool bank_aware = [] { const char *e = std::getenv("EGS_SLOT_BANKS"); return !(e && std::atoi(e) == 0); }();
-  const bool colour = bank_aware && !quad_plan;
+  const char *slot_env = std::getenv("EGS_SLOT_BANKS");
+  const bool colour = !(slot_env && std::atoi(slot_env) == 0) && !quad_plan;
   std::vector<int32_t> use_off, use_lane;
   if (colour) {
     use_off.resize((size_t)n_bodies + 1);

@@ -271,6 +271,15 @@ egs_status egs_debug_plan(int32_t n_bodies, int32_t m, const int32_t *body0,
                           int32_t *pos0, int32_t *cnt0, int32_t *pos1,
                           int32_t *cnt1);
 
+/* The LDS slot numbers of the same schedule: per constraint the slot of each side
+ * (0 = the world), and per constraint's tile the number of slots it allocates.
+ * Slot numbers decide LDS banks; a body keeps one slot in its
+ * tile.  Arrays [m], may be NULL; constraints on the cross-workgroup path get -1.  */
+egs_status egs_debug_plan_slots(int32_t n_bodies, int32_t m, const int32_t *body0,
+                                const int32_t *body1, int32_t tile_size,
+                                int32_t *lane, int32_t *slot0, int32_t *slot1,
+                                int32_t *tile_nslots);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,77 @@ def test_plan_rejects_bad_indices():
         capi.debug_plan(3, [0, 5], [1, 2])
     pl = capi.debug_plan(0, [], [])
     assert pl["n_islands"] == 0 and pl["n_tiles"] == 0
+
+
+def _modelled_conflicts(lane, tile, slot, body):
+    """Extra LDS cycles if every lane is active: per 32-lane ticket pass the largest number of
+    DIFFERENT slots on one bank (slot mod 32) minus one, per 16-lane ds_read_b128 pass likewise
+    with slot mod 16 (passes {0-3,12-15,20-27} / {4-11,16-19,28-31} of each half-wave)."""
+    tick = acc = 0
+    has = body >= 0
+    for t in np.unique(tile[has]):
+        sel = has & (tile == t)
+        for h in np.unique(lane[sel] // 32):
+            hs = sel & (lane // 32 == h)
+            li = lane[hs] % 32
+            first = (li < 4) | ((li >= 12) & (li < 16)) | ((li >= 20) & (li < 28))
+            by_bank = {}
+            for s in np.unique(slot[hs]):
+                by_bank[s % 32] = by_bank.get(s % 32, 0) + 1
+            tick += max(by_bank.values()) - 1
+            for grp in (first, ~first):
+                by_bank = {}
+                for s in np.unique(slot[hs][grp]):
+                    by_bank[s % 16] = by_bank.get(s % 16, 0) + 1
+                acc += (max(by_bank.values()) - 1) if by_bank else 0
+    return tick, acc
+
+
+@pytest.mark.parametrize("scene", ["pile", "random"])
+def test_plan_slots_are_consistent_and_bank_aware(scene, monkeypatch):
+    """LDS slot numbers: one slot per body inside its tile, none shared, slot 0 = the world,
+    at most 64 numbers beyond a dense numbering; and the bank-aware numbering removes the
+    modelled conflicts of first-use numbering (EGS_SLOT_BANKS=0) on the box pile."""
+    if scene == "pile":
+        sc = scenes.box_stack(8, 8, 8)
+        n, body0, body1 = sc["p"].shape[0], sc["body0"], sc["body1"]
+    else:
+        rng = np.random.default_rng(5)
+        n, m = 3000, 9000
+        body0 = rng.integers(0, n, m).astype(np.int32)
+        body1 = (body0 // 10 * 10 + rng.integers(0, 10, m)).astype(np.int32)   # islands of <= 10 bodies
+        body1[rng.random(m) < 0.2] = -1
+    results = {}
+    for banks in ("1", "0"):
+        monkeypatch.setenv("EGS_SLOT_BANKS", banks)
+        pl = capi.debug_plan(n, body0, body1)
+        sl = capi.debug_plan_slots(n, body0, body1)
+        tile = pl["cons_tile"]
+        assert (tile >= 0).all()
+        for side_body, side_slot in ((body0, sl["slot0"]), (body1, sl["slot1"])):
+            assert (side_slot[side_body < 0] == 0).all() and (side_slot[side_body >= 0] >= 1).all()
+            assert (side_slot < sl["tile_nslots"]).all()
+        # body -> (tile, slot) is a function, (tile, slot) -> body is one too
+        body_all = np.concatenate([body0, body1]); slot_all = np.concatenate([sl["slot0"], sl["slot1"]])
+        tile_all = np.concatenate([tile, tile]); keep = body_all >= 0
+        pairs = np.unique(np.stack([body_all[keep], tile_all[keep], slot_all[keep]], 1), axis=0)
+        assert len(np.unique(pairs[:, 0])) == len(pairs)
+        assert len(np.unique(pairs[:, 1:], axis=0)) == len(pairs)
+        # density: nslots <= bodies of the tile + 1 (world) + 64
+        for t in np.unique(tile):
+            nb = (pairs[:, 1] == t).sum()
+            ns = sl["tile_nslots"][tile == t][0]
+            assert nb + 1 <= ns <= nb + 1 + 64
+            if banks == "0":
+                assert ns == nb + 1
+        # lanes: a permutation inside each tile
+        for t in np.unique(tile):
+            ln = sl["lane"][tile == t]
+            assert len(np.unique(ln)) == len(ln) and ln.max() < 256
+        t0 = _modelled_conflicts(sl["lane"], tile, sl["slot0"], body0)
+        t1 = _modelled_conflicts(sl["lane"], tile, sl["slot1"], body1)
+        results[banks] = (t0[0] + t1[0], t0[1] + t1[1])
+    assert results["1"][0] <= results["0"][0] and results["1"][1] <= results["0"][1]
+    if scene == "pile":
+        assert results["0"][0] > 0 and results["0"][1] > 0
+        assert results["1"] == (0, 0)
