@@ -288,7 +288,9 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
   const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 &&
                      p->plan.n_patch_tiles <= max_patch_tiles(ctx) && p->patch_enabled;
   record_kernel_event(ctx, true);
-  if (patch && !resume)  // shared bodies accumulate in global memory from zero
+  // oversize islands accumulate in global memory (all bodies on the all-global kernel, shared
+  // bodies of patches): from zero, unless this launch continues the previous one
+  if (!quad && !p->plan.global.empty() && !resume)
     HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * sizeof(REAL), ctx->stream));
   if (quad || p->plan.n_tiles > 0) {
     SolveArgs<REAL> a;
@@ -334,6 +336,8 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
     }
   }
+  if (patch && p->plan.block != 256)   // patch lanes are laid out for 256-thread workgroups
+    throw std::logic_error("patch schedule built with a tile size other than 256");
   if (patch) {
     SolveArgs<REAL> a;
     a.lanes = p->p_lanes.p; a.tile_nslots = p->p_tile_nslots.p; a.tile_slot_off = p->p_tile_slot_off.p;
@@ -752,11 +756,11 @@ void ensure_tile_plan(egs_problem *p) {
     const int forced = te ? std::atoi(te) : 0;
     int tile = (forced == 64 || forced == 128 || forced == 256 || forced == 512) ? forced : (m >= kBigTileMinConstraints && p->precision == EGS_F64 && !(p->minv_iso && iso_schedule_pays(m, p->ctx->cu_count, p->precision)) ? 512 : 256);
     p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), tile);
-    if (!forced && !p->plan.global.empty()) {
-      if (tile == 256) {   // islands of 257..512 constraints: one 512-thread workgroup, all hand-offs in LDS
+    if (!p->plan.global.empty()) {
+      if (tile == 256 && !forced) {   // islands of 257..512 constraints: one 512-thread workgroup, all hand-offs in LDS
         Plan big = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), 512);
         if (big.global.empty()) p->plan = std::move(big);
-      } else {
+      } else if (tile != 256) {       // the patch kernels are 256-constraint workgroups, forced size or not
         p->plan = build_plan(n, m, p->h_body0.data(), p->h_body1.data(), 256);
       }
     }
@@ -847,9 +851,13 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
 
 egs_status check_topology(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0, const int32_t *body1) {
   if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return fail(ctx, EGS_ERR_INVALID, "bad sizes / NULL topology");
-  for (int i = 0; i < m; ++i)
+  for (int i = 0; i < m; ++i) {
+    // (the schedule builder checks the range too, but the 1-lane schedule is built lazily)
+    if (body0[i] < -1 || body0[i] >= n || body1[i] < -1 || body1[i] >= n)
+      return fail(ctx, EGS_ERR_INVALID, "body index out of range");
     if (body0[i] >= 0 && body0[i] == body1[i])
       return fail(ctx, EGS_ERR_INVALID, "constraint with the same body on both sides");
+  }
   return EGS_OK;
 }
 
@@ -1099,7 +1107,7 @@ egs_status egs_solve_blocks(egs_context *ctx, int32_t n, const double *Minv, int
                             const double *lo, const double *hi, const double *rhs, const egs_solve_params *params,
                             int32_t precision, double *x, egs_solve_stats *stats) {
   if (!ctx) return EGS_ERR_INVALID;
-  if (m > 0 && (!Minv || !J0 || !J1 || !is_eq || !lo || !hi || !rhs || !x))
+  if (m > 0 && (!Minv || !body0 || !body1 || !J0 || !J1 || !is_eq || !lo || !hi || !rhs || !x))
     return fail(ctx, EGS_ERR_INVALID, "NULL array");
   egs_problem *p = ctx->oneshot;
   const bool reuse = p && p->n == n && p->m == m && p->precision == precision &&

@@ -167,6 +167,12 @@ def test_invalid_arguments_do_not_crash(ctx):
     with pytest.raises(capi.EgsError) as e:
         capi.Problem(ctx, 2, [1], [1])                 # same body on both sides
     assert e.value.status == capi.ERR_INVALID
+    big0 = np.arange(70000, dtype=np.int32) % 1000     # past the 4-lane schedule's size: the
+    big1 = np.full(70000, -1, np.int32)                # 1-lane schedule is built lazily
+    big0[69999] = 1000
+    with pytest.raises(capi.EgsError) as e:
+        capi.Problem(ctx, 1000, big0, big1)
+    assert e.value.status == capi.ERR_INVALID
     pr = capi.Problem(ctx, 2, [0], [1])
     with pytest.raises(capi.EgsError) as e:
         pr.solve(capi.params())                        # nothing uploaded
@@ -213,6 +219,8 @@ def test_quad_and_single_lane_schedules_agree(ctx, method, monkeypatch):
 def test_quad_schedule_with_256_constraint_tiles(ctx, method):
     """Islands of 65..256 constraints still run 4 lanes per constraint, in
     1024-thread tiles; same bits as the oracle (fp64 and fp32)."""
+    if os.environ.get("EGS_QUAD") == "0":
+        pytest.skip("the 4-lane schedule is switched off (tests/tools/env_matrix.sh)")
     rng = np.random.default_rng(41)
     cases = [system_from_scene(scenes.concat([scenes.chain(int(k)) for k in (65, 200, 256, 3, 130, 90, 17)]))[0],
              random_system(rng, 40, 230, world_frac=0.1)[0],
@@ -238,6 +246,8 @@ def test_quad_schedule_with_256_constraint_tiles(ctx, method):
 def test_islands_up_to_512_constraints_stay_in_one_workgroup(ctx, method):
     """An island of 257..512 constraints runs in ONE 512-thread tile (all
     hand-offs in LDS) instead of the cross-workgroup patch path."""
+    if os.environ.get("EGS_TILE", "512") != "512":
+        pytest.skip("a smaller tile size is forced (tests/tools/env_matrix.sh)")
     rng = np.random.default_rng(43)
     s, rhs = random_system(rng, 70, 430, world_frac=0.1, connected=True)
     for K in (1, 8, 40):

@@ -67,3 +67,23 @@ def test_patches_in_fp32(ctx, method, monkeypatch):
         pr.close()
         assert st.status == capi.OK and st.n_global > 256
         assert np.array_equal(x.astype(np.float32), xo) and np.array_equal(a.astype(np.float32), ao), quad_patch
+
+
+@pytest.mark.parametrize("method", [capi.JACOBI, capi.GAUSS_SEIDEL, capi.SOR])
+def test_repeated_solves_on_one_problem_start_afresh(ctx, method, monkeypatch):
+    """A second solve on the same problem object starts from zero accumulators on every
+    oversize-island path (patches 4-lane / 1-lane, all-global), as the first one does."""
+    rng = np.random.default_rng(62)
+    s = system_from_scene(scenes.concat([scenes.chain(700), scenes.box_stack(2, 2, 3)]))[0]
+    rhs1, rhs2 = rng.uniform(-1, 1, 3 * s.m), rng.uniform(-1, 1, 3 * s.m)
+    want = [orc.fast_iterate(s, r, 0.05, method, max_iters=9, tol=0.0) for r in (rhs1, rhs2, rhs1)]
+    for patch, quad_patch in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("EGS_PATCH", patch)
+        monkeypatch.setenv("EGS_QUAD_PATCH", quad_patch)
+        pr = capi.Problem(ctx, s.n, s.body0, s.body1)
+        for rhs, (xf, af, _, _) in zip((rhs1, rhs2, rhs1), want):
+            pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+            st = pr.solve(capi.params(method=method, max_iters=9, tol=0.0, cfm=0.05))
+            assert st.status == capi.OK and st.n_global > 512
+            assert np.array_equal(pr.lambda_(), xf) and np.array_equal(pr.accumulators(), af), (patch, quad_patch)
+        pr.close()
