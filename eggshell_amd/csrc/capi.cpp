@@ -355,12 +355,12 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.cfm = cfm; a.kscale = kscale; a.sweeps = sweeps; a.resume = resume;
     a.max_slots = p->plan.patch_max_slots; a.spin_limit = kSpinLimit;
     HIPCHK(hipMemsetAsync(p->gtickets.p, 0, sizeof(uint32_t) * (size_t)(p->n > 0 ? p->n : 1), ctx->stream));
+    a.n_bodies = p->n;
+    if (p->hist_sweeps > 0) {
+      a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
+      a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
+    }
     if (p->quad_patch && p->plan.n_patch_tiles <= max_quad_patch_tiles(ctx)) {
-      a.n_bodies = p->n;
-      if (p->hist_sweeps > 0) {
-        a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
-        a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
-      }
       // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
       a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
@@ -523,10 +523,11 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   // that satisfies it.  (Tile and 4-lane kernels; oversize islands use the sweep-per-launch
   // loop below.)
   const bool quad = p->use_quad && prm->method != EGS_JACOBI;
-  // ... and body patches on the 4-lane kernel; 1-lane patches and the all-global kernel do not record
-  const bool patches4 = !quad && prm->method != EGS_JACOBI && !p->plan.global.empty() && p->patch_enabled &&
-                        p->quad_patch && p->plan.n_patch_tiles > 0 && p->plan.n_patch_tiles <= max_quad_patch_tiles(ctx);
-  const bool history = (quad || p->plan.global.empty() || patches4) && prm->max_iters > 1;
+  // ... and body patches (either kernel); the all-global kernel does not record
+  if (!quad) ensure_tile_plan(p);
+  const bool patches = !quad && prm->method != EGS_JACOBI && !p->plan.global.empty() && p->patch_enabled &&
+                       p->plan.n_patch_tiles > 0 && p->plan.n_patch_tiles <= max_patch_tiles(ctx);
+  const bool history = (quad || p->plan.global.empty() || patches) && prm->max_iters > 1;
   if (history) {
     const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
     const size_t per_sweep = (3 * m + 6 * n) * rs;

@@ -17,7 +17,9 @@ namespace egs {
 
 namespace {
 
-template <typename REAL, int METHOD>
+// HIST = true: records the per-sweep snapshots of SolveArgs::hist_x / hist_acc (tolerance-
+// terminated solves, kernels.h) -- a variant of its own so that the plain kernel keeps its registers.
+template <typename REAL, int METHOD, bool HIST>
 __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> A, uint32_t *g_tick) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
@@ -109,6 +111,21 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
           store6(ac1, a1);
         }
       }
+      if (HIST && phase >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
+        const size_t sw = (size_t)(phase - 1);
+        REAL *hx = A.hist_x + (sw * A.m + d.cidx) * 3;
+        hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+        if (has0 && ord0 == cnt0 - 1u) {   // this was the body's last update of the sweep
+          REAL *ha = A.hist_acc + (sw * A.n_bodies + gb0) * 6;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ha[q] = a0[q];
+        }
+        if (has1 && ord1 == cnt1 - 1u) {
+          REAL *ha = A.hist_acc + (sw * A.n_bodies + gb1) * 6;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ha[q] = a1[q];
+        }
+      }
       if (sh0 || sh1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -154,8 +171,11 @@ template <typename REAL>
 void launch_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint32_t *tickets, hipStream_t s) {
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
-  if (method == 1) hipLaunchKernelGGL((patch_solve_kernel<REAL, 1>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
-  else hipLaunchKernelGGL((patch_solve_kernel<REAL, 2>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
+  const bool hist = a.hist_x != nullptr;
+  if (method == 1 && hist) hipLaunchKernelGGL((patch_solve_kernel<REAL, 1, true>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
+  else if (method == 1) hipLaunchKernelGGL((patch_solve_kernel<REAL, 1, false>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
+  else if (hist) hipLaunchKernelGGL((patch_solve_kernel<REAL, 2, true>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
+  else hipLaunchKernelGGL((patch_solve_kernel<REAL, 2, false>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
 }
 
 template void launch_patch_solve<double>(const SolveArgs<double> &, int, int, uint32_t *, hipStream_t);

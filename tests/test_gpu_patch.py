@@ -87,3 +87,22 @@ def test_repeated_solves_on_one_problem_start_afresh(ctx, method, monkeypatch):
             assert st.status == capi.OK and st.n_global > 512
             assert np.array_equal(pr.lambda_(), xf) and np.array_equal(pr.accumulators(), af), (patch, quad_patch)
         pr.close()
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+@pytest.mark.parametrize("quad_patch", ["1", "0"])
+def test_tolerance_terminated_patches_stop_where_the_reference_stops(ctx, method, quad_patch, monkeypatch):
+    """The recorded-chunk stopping loop on body patches, 4-lane and 1-lane kernel: same sweep
+    count, lambda, accumulators and residual as the oracle's sweep-by-sweep loop -- stopping
+    inside a chunk, after several chunks (64 sweeps each), and at the sweep limit."""
+    monkeypatch.setenv("EGS_QUAD_PATCH", quad_patch)
+    rng = np.random.default_rng(63)
+    s = system_from_scene(scenes.concat([scenes.chain(900), scenes.box_stack(3, 3, 3), scenes.chain(300)]))[0]
+    rhs = rng.uniform(-1, 1, 3 * s.m)
+    for cfm, tol, limit in ((0.5, 1e-9, 500), (0.5, 1e-3, 500), (0.05, 1e-9, 150), (0.5, 1e-9, 5)):
+        xf, af, it, rf = orc.fast_iterate(s, rhs, cfm, method, max_iters=limit, tol=tol)
+        x, a, st = solve(ctx, s, rhs, cfm, method, limit, tol=tol)
+        assert st.status == capi.OK and st.n_global > 512
+        assert st.iterations == it, (cfm, tol, limit)
+        assert np.array_equal(x, xf) and np.array_equal(a, af)
+        assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
