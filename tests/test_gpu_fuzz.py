@@ -12,8 +12,11 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run(ctx, s, rhs, method, K, cfm, precision):
+def run(ctx, s, rhs, method, K, cfm, precision, dirty=False):
     pr = capi.Problem(ctx, s.n, s.body0, s.body1, precision)
+    if dirty:   # an earlier solve on the same object must leave nothing behind
+        pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs[::-1].copy())
+        pr.solve(capi.params(method=method, max_iters=3, tol=0.0, cfm=max(cfm, 0.01)))
     pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
     st = pr.solve(capi.params(method=method, max_iters=K, tol=0.0, cfm=cfm))
     x, a = pr.lambda_(), pr.accumulators()
@@ -45,7 +48,7 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
             monkeypatch.setenv("EGS_QUAD", quad)
             monkeypatch.setenv("EGS_PATCH", patch)
             monkeypatch.setenv("EGS_QUAD_PATCH", qpatch)
-            x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64)
+            x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64, dirty=case % 2 == 1)
             assert st.status == capi.OK
             assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, quad, patch)
         monkeypatch.setenv("EGS_QUAD", "1"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
@@ -59,5 +62,5 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
             xr, ar, it, rr = orc.fast_iterate(s, rhs, cfm, method, max_iters=cap, tol=tol, check_every=every)
             assert st.iterations == it, (seed, case, "tol", st.iterations, it)
             assert np.array_equal(xt, xr, equal_nan=True) and np.array_equal(at, ar, equal_nan=True), (seed, case, "tol")
-        x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F32)
+        x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F32, dirty=case % 2 == 0)
         assert np.array_equal(x.astype(np.float32), xo, equal_nan=True) and np.array_equal(a.astype(np.float32), ao, equal_nan=True), (seed, case, "f32")   # a diverging cfm = 0 run overflows to the same NaNs on both sides
