@@ -399,6 +399,11 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     g.resume = resume;
     g.method = method;
     g.spin_limit = kSpinLimit;
+    g.m = p->m;
+    if (p->hist_sweeps > 0 && method != EGS_JACOBI) {
+      g.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
+      g.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
+    }
     launch_global_solve<REAL>(g, ctx->stream);
   }
   record_kernel_event(ctx, false);
@@ -520,14 +525,12 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   // Fast form, same result: sweeps run in chunks of up to 64 per launch while the kernels
   // record x and the per-body accumulators after every sweep; one more kernel evaluates the
   // stopping test of every recorded sweep and ONE read-back per chunk finds the first sweep
-  // that satisfies it.  (Tile and 4-lane kernels; oversize islands use the sweep-per-launch
-  // loop below.)
+  // that satisfies it.
   const bool quad = p->use_quad && prm->method != EGS_JACOBI;
-  // ... and body patches (either kernel); the all-global kernel does not record
+  // ... and oversize islands on the patch kernels or the all-global kernel.  Only Jacobi on
+  // oversize islands, which is a launch per sweep anyway, takes the plain loop below.
   if (!quad) ensure_tile_plan(p);
-  const bool patches = !quad && prm->method != EGS_JACOBI && !p->plan.global.empty() && p->patch_enabled &&
-                       p->plan.n_patch_tiles > 0 && p->plan.n_patch_tiles <= max_patch_tiles(ctx);
-  const bool history = (quad || p->plan.global.empty() || patches) && prm->max_iters > 1;
+  const bool history = (quad || p->plan.global.empty() || prm->method != EGS_JACOBI) && prm->max_iters > 1;
   if (history) {
     const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
     const size_t per_sweep = (3 * m + 6 * n) * rs;

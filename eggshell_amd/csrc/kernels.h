@@ -58,6 +58,9 @@ struct GlobalArgs {
   int32_t sweeps, resume, method;
   int32_t mode;                // 0 = full sweeps, 1 = ordered accumulate of dx only
   uint32_t spin_limit;
+  // per-sweep snapshots for tolerance-terminated solves, as in SolveArgs (NULL = off)
+  int32_t m = 0, pad1 = 0;     // all constraints of the problem (hist_x stride)
+  REAL *hist_x = nullptr, *hist_acc = nullptr;
 };
 
 struct AssembleArgs {

@@ -680,9 +680,9 @@ __global__ void __launch_bounds__(256) global_solve_kernel(const GlobalArgs<REAL
       const bool has0 = d.body0 >= 0, has1 = d.body1 >= 0;
       const unsigned cnt0 = d.cnt0, cnt1 = d.cnt1, pos0 = d.pos0, pos1 = d.pos1;
       unsigned want0, want1;
+      const unsigned o0 = backward ? cnt0 - 1u - pos0 : pos0, o1 = backward ? cnt1 - 1u - pos1 : pos1;
       if (p == 0) { want0 = pos0; want1 = pos1; }
       else {
-        const unsigned o0 = backward ? cnt0 - 1u - pos0 : pos0, o1 = backward ? cnt1 - 1u - pos1 : pos1;
         want0 = (rel ? 0u : cnt0) + (unsigned)(p - 1) * cnt0 + o0;
         want1 = (rel ? 0u : cnt1) + (unsigned)(p - 1) * cnt1 + o1;
       }
@@ -724,6 +724,19 @@ __global__ void __launch_bounds__(256) global_solve_kernel(const GlobalArgs<REAL
           acc_add(a1, c.B1, dx);
 #pragma unroll
           for (int q = 0; q < 6; ++q) gst(A.acc + (size_t)d.body1 * 6 + q, a1[q]);
+        }
+        if (A.hist_x && p >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
+          const size_t sw = (size_t)(p - 1);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) A.hist_x[(sw * A.m + d.cidx) * 3 + r] = A.x[(size_t)d.cidx * 3 + r];
+          if (has0 && o0 == cnt0 - 1u) {   // this was the body's last update of the sweep
+#pragma unroll
+            for (int q = 0; q < 6; ++q) A.hist_acc[(sw * A.n_bodies + d.body0) * 6 + q] = a0[q];
+          }
+          if (has1 && o1 == cnt1 - 1u) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) A.hist_acc[(sw * A.n_bodies + d.body1) * 6 + q] = a1[q];
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

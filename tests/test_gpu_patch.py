@@ -90,11 +90,13 @@ def test_repeated_solves_on_one_problem_start_afresh(ctx, method, monkeypatch):
 
 
 @pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
-@pytest.mark.parametrize("quad_patch", ["1", "0"])
-def test_tolerance_terminated_patches_stop_where_the_reference_stops(ctx, method, quad_patch, monkeypatch):
-    """The recorded-chunk stopping loop on body patches, 4-lane and 1-lane kernel: same sweep
-    count, lambda, accumulators and residual as the oracle's sweep-by-sweep loop -- stopping
-    inside a chunk, after several chunks (64 sweeps each), and at the sweep limit."""
+@pytest.mark.parametrize("patch,quad_patch", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_tolerance_terminated_patches_stop_where_the_reference_stops(ctx, method, patch, quad_patch, monkeypatch):
+    """The recorded-chunk stopping loop on oversize islands -- body patches on the 4-lane and
+    the 1-lane kernel, and the all-global kernel: same sweep count, lambda, accumulators and
+    residual as the oracle's sweep-by-sweep loop -- stopping inside a chunk, after several
+    chunks (64 sweeps each), and at the sweep limit."""
+    monkeypatch.setenv("EGS_PATCH", patch)
     monkeypatch.setenv("EGS_QUAD_PATCH", quad_patch)
     rng = np.random.default_rng(63)
     s = system_from_scene(scenes.concat([scenes.chain(900), scenes.box_stack(3, 3, 3), scenes.chain(300)]))[0]
