@@ -1,5 +1,11 @@
-import sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+"""Debug aid: the 64x64 wall (one 40k-contact island) solved three times in a row through the
+one-shot entry for K = 1, 2, 10, 100 sweeps, mismatches against the oracle printed per run.
+Run with EGS_PATCH=0 to exercise the all-global kernel (this is how the stale-accumulator bug
+of repeated solves was located)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from eggshell_amd import capi, scenes
 from helpers import system_from_scene
 from oracle import oracle as orc
