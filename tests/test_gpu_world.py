@@ -98,3 +98,35 @@ def test_free_fall_without_constraints(ctx):
     assert abs(v[0, 2] - (-9.8 * 0.1)) < 1e-12
     assert abs(pos[0, 2] - (5.0 - 0.5 * 9.8 * 0.1 * 0.1)) < 1e-12   # midpoint rule is exact for constant g
     wd.close()
+
+
+@pytest.mark.parametrize("precision", [capi.F64, capi.F32])
+def test_world_step_equals_problem_step(ctx, precision):
+    """One world step = collide + the device-resident problem step + advance, in either solve
+    precision: same contact list, lambda, velocities and positions as the pieces called one by
+    one (the pieces are each checked against the oracle elsewhere)."""
+    sc = scenes.box_stack(4, 4, 3)
+    n = sc["p"].shape[0]
+    Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+    f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+    prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=40, tol=0.0, cfm=0.01)
+    wd = capi.World(ctx, n, precision)
+    wd.set_bodies(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
+    pr = None
+    pos, R, v, w = sc["p"], sc["R"], sc["v"], sc["w"]
+    for step in range(3):
+        wd.step(0.005, 0.2, prm)
+        b0, b1, data = ctx.update_contacts(pos, R)
+        wb0, wb1, wdata = wd.contacts()
+        assert np.array_equal(wb0, b0) and np.array_equal(wb1, b1) and np.array_equal(wdata, data)
+        pr = capi.Problem(ctx, n, b0, b1, precision)
+        pr.set_state(pos, R, v, w, Minv, f_ext)
+        pr.set_constraints(np.full(len(b0), capi.CONTACT_BOX, np.int32), data)
+        pr.step(0.005, 0.2, prm)
+        assert np.array_equal(wd.lambda_(), pr.lambda_()), step
+        pr.advance(0.005)
+        pos, R, v, w = pr.state()
+        pr.close()
+        wpos, wR, wv, ww = wd.bodies()
+        assert np.array_equal(wpos, pos) and np.array_equal(wR, R) and np.array_equal(wv, v) and np.array_equal(ww, w), step
+    wd.close()
