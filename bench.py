@@ -3,20 +3,38 @@
 
 A "step" is one whole pass of the hot path over one batch of synthetic input:
 device-side Jacobian assembly (K1-K4) + projected Gauss-Seidel sweeps (K5-K8) +
-velocity update (K9) for `--batch` independent C3 piles resident in HBM
-(16x16x16 boxes = 4096 bodies, 16384 contacts with the friction box, 100
-sweeps, fp64).  Inputs are uploaded before the timed region; nothing is copied
-back inside it.  `value` = pile-steps per second summed over all GPUs.
+velocity update (K9).  Inputs are uploaded before the timed region; nothing is
+copied back inside it.
 
-  python bench.py --gpus 1 --steps 50 --warmup 5
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+Headline (`value`), BASELINE config 3: `--batch` independent 16x16x16 box piles
+(4096 bodies, 16384 contacts with the friction box, 100 sweeps, fp64) resident
+per GPU, weak scaling (every rank its own piles).  `--workload c4` makes BASELINE
+config 4 the headline instead: 1024 independent 64-body ensembles (fp32, 50
+sweeps), SHARDED over the ranks (eggshell_amd.dist.shard_range), strong scaling.
+
+On one GPU the same JSON line carries every other BASELINE configuration and
+the kernels the north star names, each with the physical bound that applies:
+  single_pile   one C3 pile (the dependency chain of a pile: latency)
+  matvec        the stand-alone block-sparse J M^-1 J^T product on C3 x batch
+                (the one kernel of the path that streams: HBM roofline)
+  c2            256-body pile, 50 sweeps
+  c4            1024 x 64-body ensembles, fp32
+  coupled       ONE island of ~16k contacts (a running-bond wall): what a
+                genuinely coupled pile costs
+  c5            dense direct LCP, N = 2048 (MFMA fp64), CPU dense oracle beside it
+  cpu_baseline  the CPU port of the same step on the host cores
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
       --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: independent piles are sharded one process per GPU (weak scaling, no
-data-path collective); RCCL carries one statistics reduction per run.
+Multi-GPU: one process per GPU, no data-path collective; RCCL carries one
+statistics reduction per run.
 """
 import argparse
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -30,7 +48,15 @@ from eggshell_amd import capi, scenes  # noqa: E402
 from eggshell_amd import dist as egs_dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy rate 6290
-BYTES_PER_CONTACT_SWEEP = {"f64": 768, "f32": 388}
+CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md chip-level parameters)
+N_CU = 256
+BYTES_PER_CONTACT_SWEEP = {"f64": 768, "f32": 388}   # the re-stream-every-sweep accounting
+FLOPS_PER_CONTACT_SWEEP = 230
+# compulsory HBM bytes of ONE stand-alone product per constraint:
+# J0 + J1 (36 REAL), x and y (3 + 3 REAL), the schedule entry (12 B lane + 4 B amortised slot
+# tables); per body the 6x6 block of M^-1 (36 REAL) and its 20-byte slot.
+MV_BYTES_PER_CONTACT = {"f64": 42 * 8 + 16, "f32": 42 * 4 + 16}
+MV_BYTES_PER_BODY = {"f64": 36 * 8 + 20, "f32": 36 * 4 + 20}
 
 WORKLOADS = {
     # name: (nx, ny, nz, sweeps, precision, dt)
@@ -38,6 +64,7 @@ WORKLOADS = {
     "c2": (8, 8, 4, 50, "f64", 5e-3),
     "c4": (4, 4, 4, 50, "f32", 5e-3),
 }
+C4_ENSEMBLES = 1024
 
 
 def host_mass_and_force(sc):
@@ -56,16 +83,24 @@ def host_mass_and_force(sc):
     return Minv.reshape(n, 36), f
 
 
+def load_profile_json(name):
+    """Newest profiles/r*/<name> (measured on the GPU box, committed): PMC traffic, microbenchmarks."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name))):
+        try:
+            best = (json.load(open(f)), os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def measured_traffic_per_contact(kernel):
-    """HBM bytes per contact per launch of the solve kernel, measured with
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 FETCH_SIZE
-    correction applied) on this same command; see profiles/*/pmc_traffic.json."""
-    import glob
+    """HBM bytes per contact per launch of `kernel`, measured with rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE (separate passes, gfx950 FETCH_SIZE x2 correction) on this bench command."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
         try:
-            d = json.load(open(f))
-            v = d["hbm_bytes_per_contact_per_launch"].get(kernel)
+            v = json.load(open(f))["hbm_bytes_per_contact_per_launch"].get(kernel)
             if v:
                 best = (float(v), os.path.relpath(f, ROOT))
         except Exception:
@@ -73,9 +108,318 @@ def measured_traffic_per_contact(kernel):
     return best
 
 
+def sweep_critical_path(body0, body1, sweeps):
+    """Length, in dependent constraint updates, of the list-order sweep's critical path:
+    depth of one sweep's dependency DAG (a constraint waits for the previous constraint of
+    each of its bodies) + (sweeps - 1) x the largest per-body constraint count (a body's
+    constraints run one after the other in every sweep).  One island's worth of topology."""
+    n = int(max(body0.max(), body1.max())) + 1
+    last = np.zeros(n + 1, np.int64)
+    cnt = np.zeros(n + 1, np.int64)
+    depth = 0
+    for a, b in zip(body0.tolist(), body1.tolist()):
+        lv = max(last[a] if a >= 0 else 0, last[b] if b >= 0 else 0)
+        if a >= 0:
+            last[a] = lv + 1; cnt[a] += 1
+        if b >= 0:
+            last[b] = lv + 1; cnt[b] += 1
+        depth = max(depth, lv + 1)
+    return int(depth + (sweeps - 1) * cnt.max()), int(depth), int(cnt.max())
+
+
+def solve_kernel_name(st):
+    if st.schedule & capi.SCHED_QUAD:
+        return "quad_solve_kernel"
+    if st.schedule & capi.SCHED_QUAD_PATCHES:
+        return "quad_solve_kernel(patches)"
+    if st.schedule & capi.SCHED_LANE_PATCHES:
+        return "patch_solve_kernel"
+    if st.schedule & capi.SCHED_ALL_GLOBAL:
+        return "global_solve_kernel"
+    return "tile_solve_kernel"
+
+
+def resident_tiles_per_cu(st, prec):
+    """Workgroup tiles one CU keeps resident (register-limited)."""
+    if st.schedule & capi.SCHED_QUAD:
+        return {64: 5, 128: 2, 256: 1}.get(st.tile_constraints, 1)      # 96 VGPRs, 4 lanes per constraint
+    if st.schedule & (capi.SCHED_QUAD_PATCHES | capi.SCHED_ALL_GLOBAL):
+        return 1
+    if st.schedule & capi.SCHED_LANE_PATCHES:
+        return 2
+    if st.schedule & capi.SCHED_ISO:
+        return 4 if prec == "f32" else 3
+    if prec == "f32":
+        return 3
+    return {64: 8, 128: 4, 256: 2, 512: 1}.get(st.tile_constraints, 1)   # 232 VGPRs: 2 wavefronts per SIMD
+
+
+def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit):
+    """The bounds of one solve launch.  `roofline` (bound = latency): the launch cannot end before
+    rounds x critical-path updates x t_update_min -- rounds = how often the CUs' resident tiles
+    turn over, t_update_min = ONE always-ready constraint update of this kernel's instruction
+    sequence, measured alone on a CU (tools/microbench.hip).  `roofline_hbm`: HBM bytes actually
+    moved (rocprofv3 counters) against the HBM peak.  Plus achieved fp64 FLOP/s and the SURVEY 8(d)
+    re-stream-every-sweep figure as information."""
+    upd = float(m) * sweeps
+    achieved = upd / (kernel_ms * 1e-3)
+    mb = load_profile_json("microbench.json")
+    base = kernel.split("(")[0]
+    key = {"tile_solve_kernel": "update_iso_w1_a1_ticks" if st.schedule & capi.SCHED_ISO else "update_reg_w1_a1_ticks"}.get(base)
+    t_upd_cycles, src = None, None
+    if mb and key and key in mb[0]:
+        t_upd_cycles, src = float(mb[0][key]), "%s:%s (one always-ready update, alone on a CU, shader cycles)" % (mb[1], key)
+    if t_upd_cycles is None:
+        # DESIGN.md section 5: two LDS round trips + the dependent fp64 chain + the hand-off stores
+        t_upd_cycles, src = (300.0 if base == "quad_solve_kernel" else 560.0), "DESIGN.md section 5 estimate (no microbench.json for this kernel)"
+    t_upd = t_upd_cycles / (CLOCK_GHZ * 1e3)     # us
+    tiles_cu = resident_tiles_per_cu(st, prec)
+    n_tiles = max(st.n_tiles, 1)
+    rounds = max(1, math.ceil(n_tiles / float(tiles_cu * N_CU)))
+    t_min_ms = rounds * crit[0] * t_upd * 1e-3
+    lat = {
+        "bound": "latency", "unit": "constraint-updates/s", "achieved": achieved, "peak": upd / (t_min_ms * 1e-3),
+        "frac": t_min_ms / kernel_ms, "traffic": None,
+        "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches,
+        "model": "t_kernel >= rounds x critical_path x t_update_min",
+        "rounds": rounds, "resident_tiles_per_cu": tiles_cu, "tiles": n_tiles,
+        "critical_path_updates": crit[0], "sweep_depth": crit[1], "per_body_period": crit[2],
+        "t_update_min_us": t_upd, "t_update_min_source": src,
+        "achieved_fp64_tflops" if prec == "f64" else "achieved_fp32_tflops": achieved * FLOPS_PER_CONTACT_SWEEP / 1e12,
+        "algorithmic_restream_gbs": achieved * BYTES_PER_CONTACT_SWEEP[prec] / 1e9,
+        "note": "algorithmic_restream_gbs = updates/s x %d B (SURVEY 8d: a design that re-streams the system every sweep); "
+                "J blocks and accumulators stay in VGPRs/LDS across sweeps, so it is information, not a bound" % BYTES_PER_CONTACT_SWEEP[prec],
+    }
+    tr = measured_traffic_per_contact(base)
+    hbm = None
+    if tr:
+        traffic = tr[0] * m
+        gbs = traffic / (kernel_ms * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+               "traffic": traffic, "traffic_source": "%s: %.0f B per contact per launch of %s (rocprofv3 --pmc FETCH_SIZE x2 + "
+               "WRITE_SIZE, separate passes)" % (tr[1], tr[0], base)}
+        lat["traffic"] = traffic
+    return lat, hbm
+
+
+def build_problem(ctx, sc, precision):
+    n = sc["p"].shape[0]
+    Minv, f_ext = host_mass_and_force(sc)
+    t_plan = time.perf_counter()
+    pr = capi.Problem(ctx, n, sc["body0"], sc["body1"], precision)
+    t_plan = time.perf_counter() - t_plan
+    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
+    pr.set_constraints(sc["kind"], sc["data"])
+    return pr, t_plan
+
+
+def time_region(ctx, fn, steps, warmup, torch=None, tdist=None, world=1):
+    """W untimed calls, then exactly `steps` calls between barrier + synchronize on both sides."""
+    for _ in range(warmup):
+        fn()
+    ctx.synchronize()
+    if torch is not None:
+        torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    ctx.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.synchronize()
+    if torch is not None:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tdist.barrier()
+    ksum_ms, klaunches = ctx.kernel_time(reset=True)
+    return elapsed, ksum_ms / max(klaunches, 1), klaunches
+
+
+def run_piles(ctx, workload, seeds, method, steps, warmup, torch=None, tdist=None, world=1):
+    """`len(seeds)` piles of `workload` in one problem; time exactly `steps` steps."""
+    nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
+    piles = [scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=int(sd), origin=(0.0, 100.0 * k)) for k, sd in enumerate(seeds)]
+    sc = scenes.concat(piles) if len(piles) > 1 else piles[0]
+    m = sc["kind"].shape[0]
+    pr, t_plan = build_problem(ctx, sc, capi.F32 if prec == "f32" else capi.F64)
+    prm = capi.params(method=method, max_iters=sweeps, tol=0.0, cfm=0.01)
+    elapsed, kernel_ms, launches = time_region(ctx, lambda: pr.step(dt, 0.2, prm), steps, warmup, torch, tdist, world)
+    st = pr.stats()          # the stall flag is sticky: this covers every step of the run
+    # a pile is nx*ny independent columns: the critical path is one column's
+    col = nx * ny
+    one = piles[0]
+    keep = (np.where(one["body0"] >= 0, one["body0"], one["body1"]) % col) == 0
+    crit = sweep_critical_path(np.where(one["body0"][keep] >= 0, one["body0"][keep] // col, -1),
+                               np.where(one["body1"][keep] >= 0, one["body1"][keep] // col, -1), sweeps)
+    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, prec, st, crit)
+    return dict(elapsed=elapsed, n=sc["p"].shape[0], m=m, sweeps=sweeps, prec=prec, dt=dt, stats=st, t_plan=t_plan,
+                roofline=lat, roofline_hbm=hbm, shape=(nx, ny, nz), problem=pr, scene=sc, piles=len(piles))
+
+
+def leg_from_run(r, steps, unit="pile-steps/s", note=None):
+    out = {"value": r["piles"] * steps / r["elapsed"], "unit": unit, "ms_per_step": r["elapsed"] / steps * 1e3,
+           "contact_iters_per_sec": float(r["m"]) * r["sweeps"] * steps / r["elapsed"],
+           "contacts": r["m"], "sweeps": r["sweeps"], "dtype": r["prec"], "islands": r["stats"].n_islands,
+           "failed": r["stats"].status != capi.OK, "max_residual": r["stats"].residual,
+           "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"]}
+    if note:
+        out["note"] = note
+    return out
+
+
+def replicate(sc, times):
+    """`times` copies of a scene side by side (body indices offset; numpy only, so a million contacts
+    take a moment instead of a minute of Python loops)."""
+    n = sc["p"].shape[0]
+    out = {}
+    for k in ("p", "R", "v", "w", "mass", "I_body", "kind", "data"):
+        out[k] = np.concatenate([sc[k]] * times)
+    shift = np.repeat(np.arange(times, dtype=np.int64) * 1000.0, n)
+    out["p"] = out["p"].copy(); out["p"][:, 1] += shift
+    out["data"] = out["data"].copy(); out["data"][:, 1] += np.repeat(np.arange(times) * 1000.0, sc["kind"].shape[0])
+    off = np.repeat(np.arange(times, dtype=np.int64) * n, sc["kind"].shape[0])
+    b0, b1 = np.tile(sc["body0"], times).astype(np.int64), np.tile(sc["body1"], times).astype(np.int64)
+    out["body0"] = np.where(b0 >= 0, b0 + off, -1).astype(np.int32)
+    out["body1"] = np.where(b1 >= 0, b1 + off, -1).astype(np.int32)
+    return out
+
+
+def matvec_measure(ctx, pr, m, n, prec, steps, warmup):
+    elapsed, kernel_ms, launches = time_region(ctx, lambda: pr.matvec(None, capi.MV_FULL, 0.01, 1.0, fetch=False), steps, warmup)
+    alg = float(m) * MV_BYTES_PER_CONTACT[prec] + float(n) * MV_BYTES_PER_BODY[prec]
+    gbs = alg / (kernel_ms * 1e-3) / 1e9
+    tr = measured_traffic_per_contact("matvec_tile_kernel")
+    return {
+        "value": steps / elapsed, "unit": "products/s", "ms_per_product": elapsed / steps * 1e3, "contacts": m, "bodies": n,
+        "contacts_per_sec": float(m) * steps / elapsed,
+        "roofline": {"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": (tr[0] * m) if tr else None,
+                     "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % (tr[1], tr[0])) if tr else None,
+                     "kernel": "matvec_tile_kernel", "kernel_ms": kernel_ms, "launches": launches,
+                     "algorithmic_bytes_per_launch": alg}}
+
+
+def matvec_leg(ctx, r, steps, warmup, big_piles=64):
+    """The stand-alone product y = (J M^-1 J^T + cfm I) lambda (sparse::CalculateSparseJMJtX): the kernel of the
+    path that streams, hence the HBM roofline.  Measured on `big_piles` C3 piles (1 M contacts, ~450 MB per
+    product: beyond the 256 MiB Infinity Cache, so every launch really reads HBM) and, for comparison, on the
+    resident problem of the main leg (170 MB: re-read from the Infinity Cache launch after launch)."""
+    prec = r["prec"]
+    one = scenes.box_stack(*r["shape"], jitter=1e-3, seed=1)
+    sc = replicate(one, big_piles)
+    pr, _ = build_problem(ctx, sc, capi.F32 if prec == "f32" else capi.F64)
+    pr.assemble(r["dt"], 0.2)
+    pr.solve(capi.params(method=capi.GAUSS_SEIDEL, max_iters=1, tol=0.0, cfm=0.01), want_stats=False)   # a non-trivial lambda to multiply
+    out = matvec_measure(ctx, pr, sc["kind"].shape[0], sc["p"].shape[0], prec, steps, warmup)
+    pr.close()
+    out["workload"] = "%d C3 piles in one problem (identical copies), full product, lambda of one GS sweep" % big_piles
+    out["roofline"]["note"] = ("algorithmic bytes = compulsory traffic of one product: %d B per contact (J0, J1, x, y, schedule entry) + "
+                               "%d B per body (M^-1 block, slot): every byte read or written once; SURVEY 8(d)'s 768 B figure also "
+                               "counts the body sums, which stay in LDS here" % (MV_BYTES_PER_CONTACT[prec], MV_BYTES_PER_BODY[prec]))
+    small = matvec_measure(ctx, r["problem"], r["m"], r["n"], prec, steps, warmup)
+    out["infinity_cache_resident"] = {"contacts": r["m"], "ms_per_product": small["ms_per_product"],
+                                      "achieved_gbs": small["roofline"]["achieved"], "kernel_ms": small["roofline"]["kernel_ms"],
+                                      "note": "the main leg's problem (%.0f MB per product < 256 MiB): served by the Infinity Cache, "
+                                              "not a statement about HBM" % (small["roofline"]["algorithmic_bytes_per_launch"] / 1e6)}
+    return out
+
+
+def c4_shard_seeds(rank, world):
+    """BASELINE config 4: ensembles 0..1023, seeds = the global ensemble index, contiguous shards."""
+    begin, end = egs_dist.shard_range(C4_ENSEMBLES, rank, world)
+    return list(range(begin, end))
+
+
+def coupled_leg(ctx, method, steps, warmup, cpu_seconds):
+    """ONE island: a 41 x 40 running-bond wall (every brick rests on two), ~16k contacts, GS 100 sweeps fp64."""
+    from oracle import oracle as orc
+    sc = scenes.brick_wall(41, 40)
+    b0, b1, data = ctx.update_contacts(sc["p"], sc["R"])
+    sc.update(kind=np.full(len(b0), capi.CONTACT_BOX, np.int32), body0=b0, body1=b1, data=data)
+    m, sweeps, dt = len(b0), 100, 5e-3
+    pr, t_plan = build_problem(ctx, sc, capi.F64)
+    prm = capi.params(method=method, max_iters=sweeps, tol=0.0, cfm=0.01)
+    elapsed, kernel_ms, launches = time_region(ctx, lambda: pr.step(dt, 0.2, prm), steps, warmup)
+    st = pr.stats()
+    crit = sweep_critical_path(sc["body0"], sc["body1"], sweeps)
+    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, "f64", st, crit)
+    out = {"value": steps / elapsed, "unit": "pile-steps/s", "ms_per_step": elapsed / steps * 1e3, "bodies": sc["p"].shape[0],
+           "contacts": m, "islands": st.n_islands, "sweeps": sweeps, "contact_iters_per_sec": float(m) * sweeps * steps / elapsed,
+           "failed": st.status != capi.OK, "roofline": lat, "roofline_hbm": hbm,
+           "workload": "41 x 40 running-bond brick wall on the ground, contacts from the device collider: ONE island"}
+    if cpu_seconds > 0:
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+        done, t0 = 0, time.perf_counter()
+        while True:
+            J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+            s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+            rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
+            x, a, _, _ = orc.fast_iterate(s, rhs, 0.01, method, max_iters=sweeps, tol=0.0)
+            orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= cpu_seconds or done >= 200:
+                break
+        out["cpu_baseline"] = {"value": done / el, "unit": "pile-steps/s", "cores": 1, "kind": "port",
+                               "sample": "%d steps of the same wall, oracle/ fast O(nnz) port, 1 thread, %.1f s" % (done, el)}
+    pr.close()
+    return out
+
+
+def c5_problem(N, seed=0):
+    """SURVEY 8(d) C5 recipe: A = M^T M, M ~ U(-1,1) (GenerateSPDMatrix, utils.cc:203-215; + 1e-3 I if
+    ill-conditioned), b ~ U(-1,1), C ~ Bernoulli(1/2), lo = 0, hi = inf."""
+    rng = np.random.default_rng(seed)
+    M = rng.uniform(-1, 1, (N, N))
+    A = M.T @ M
+    if N <= 512 and not np.linalg.cond(A) < 1e7:
+        A = A + 1e-3 * np.eye(N)
+    elif N > 512:
+        A = A + 1e-3 * np.eye(N)     # the condition check itself (an SVD of 2048^2) is not part of the timed path
+    b = rng.uniform(-1, 1, N)
+    C = (rng.uniform(size=N) < 0.5).astype(np.uint8)
+    return A, b, C, np.zeros(N), np.full(N, np.inf)
+
+
+def c5_leg(ctx, cpu_seconds):
+    """BASELINE config 5: dense direct LCP (Lcp::MixedConstraintsSolver semantics), N = 2048, fp64 MFMA."""
+    from oracle import oracle as orc
+    out = {}
+    for N, mode, reps in ((2048, 2, 3), (512, 2, 3), (512, 0, 1), (256, 0, 1)):
+        A, b, C, lo, hi = c5_problem(N)
+        ok, x, w, piv = ctx.mixed_constraints_solve(A, b, C, lo, hi, use_bounds=mode)    # warm-up (code objects, buffers)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ok, x, w, piv = ctx.mixed_constraints_solve(A, b, C, lo, hi, use_bounds=mode)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        ne = int(C.sum()); ni = N - ne
+        flops = ne ** 3 / 3.0 + 2.0 * ne * ne * ni + ni * ni * ne       # SURVEY 8(d): the Schur stage
+        resid = float(np.abs(A @ x - b - w).max())
+        key = "N%d_%s" % (N, "block_pivoting" if mode == 2 else "reference_rule")
+        out[key] = {"ms_per_solve": ms, "ok": bool(ok), "pivots": int(piv), "kkt_residual": resid,
+                    "schur_gflop": flops / 1e9, "achieved_tflops_schur_only": flops / (ms * 1e-3) / 1e12,
+                    "includes": "pageable upload of A (%.1f MB) + solve + download" % (A.nbytes / 1e6)}
+    out["note"] = ("reference_rule = Murty single-index principal pivoting as lcp.cc:157-274 (cap min(1000, 2^n) pivots: it "
+                   "cannot finish N >= 1024 mixed problems, in the reference as here); block_pivoting = same solution, tens of "
+                   "factorisations.  Launch-bound at these sizes: ~3 dependent launches per 64-column panel; fp64 MFMA peak is "
+                   "not in the local guides, so TFLOP/s is reported, not a fraction")
+    if cpu_seconds > 0:
+        cpu = {}
+        for N in (256, 512):
+            A, b, C, lo, hi = c5_problem(N)
+            t0 = time.perf_counter()
+            ok, x, w, piv = orc.mixed_constraints(A, b, C, lo, hi, 0)
+            cpu["N%d" % N] = {"ms_per_solve": (time.perf_counter() - t0) * 1e3, "ok": bool(ok), "pivots": int(piv)}
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms/solve", "sample": "oracle/lcp_dense.c (restated "
+                               "MixedConstraintsSolver + Murty, lcp.cc:141-336), one solve each", **cpu}
+    return out
+
+
 def cpu_baseline(workload, budget_s):
-    """Single-thread CPU port (oracle/, the fast O(nnz) sequential PGS in list
-    order + assembly + velocity update) on ONE pile of the same workload."""
+    """Single-thread CPU port (oracle/, the fast O(nnz) sequential PGS in list order + assembly +
+    velocity update) on ONE pile of the same workload."""
     from oracle import oracle as orc
     nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
     sc = scenes.box_stack(nx, ny, nz)
@@ -95,78 +439,52 @@ def cpu_baseline(workload, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or done >= 1000:
             break
-    return {"value": done / el, "unit": "pile-steps/s", "cores": 1, "kind": "port",
+    unit = "ensemble-steps/s" if workload == "c4" else "pile-steps/s"
+    return {"value": done / el, "unit": unit, "cores": 1, "kind": "port",
             "sample": "%d steps of one %dx%dx%d pile (%d contacts, GS %d sweeps, %s), oracle/ fast O(nnz) "
                       "port, gcc -O2, 1 thread, %.1f s" % (done, nx, ny, nz, s.m, sweeps, prec, el)}
 
 
-def run_workload(ctx, workload, batch, method, steps, warmup, rank, torch, tdist, world):
-    """Build `batch` piles, upload, warm up, time exactly `steps` steps.  Returns a dict."""
-    nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
-    precision = capi.F32 if prec == "f32" else capi.F64
-    # `batch` independent piles per GPU; seeds differ per rank and pile (C4 style
-    # jitter of whole columns) so no two piles are identical.
-    piles = [scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=rank * batch + b + 1,
-                              origin=(0.0, 100.0 * b)) for b in range(batch)]
-    sc = scenes.concat(piles) if batch > 1 else piles[0]
-    n, m = sc["p"].shape[0], sc["kind"].shape[0]
-    Minv, f_ext = host_mass_and_force(sc)
-    t_plan = time.perf_counter()
-    pr = capi.Problem(ctx, n, sc["body0"], sc["body1"], precision)
-    t_plan = time.perf_counter() - t_plan
-    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
-    pr.set_constraints(sc["kind"], sc["data"])
-    prm = capi.params(method=method, max_iters=sweeps, tol=0.0, cfm=0.01)
-    for _ in range(warmup):
-        pr.step(dt, 0.2, prm)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        tdist.barrier()
-    ctx.kernel_time(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pr.step(dt, 0.2, prm)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tdist.barrier()
-    ksum_ms, klaunches = ctx.kernel_time(reset=True)
-    st = pr.stats()
-    pr.close()
-    kernel_ms = ksum_ms / max(klaunches, 1)
-    alg_bytes = float(m) * sweeps * BYTES_PER_CONTACT_SWEEP[prec]   # per launch (one rank's batch)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = measured_traffic_per_contact("tile_solve_kernel")
-    roof = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": (traffic[0] * m) if traffic else None,
-        "traffic_source": ("%s: %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                           "measured on the tile_solve_kernel of this bench command)" % (traffic[1], traffic[0])) if traffic else None,
-        "kernel": "quad_solve_kernel (+cons_prepare)" if st.reserved == 1 else "tile_solve_kernel",
-        "kernel_ms": kernel_ms, "launches": klaunches, "algorithmic_bytes_per_launch": alg_bytes,
-        "note": "algorithmic bytes = contacts x sweeps x %d B (SURVEY 8d); J blocks and body accumulators stay in "
-                "VGPRs/LDS across sweeps, so the achieved figure can exceed HBM peak" % BYTES_PER_CONTACT_SWEEP[prec],
-    }
-    return dict(elapsed=elapsed, n=n, m=m, sweeps=sweeps, prec=prec, dt=dt, stats=st, t_plan=t_plan, roofline=roof,
-                shape=(nx, ny, nz))
+def cpu_literal_baseline(budget_s):
+    """SURVEY 8(d) baseline (i): the LITERAL O(m^2) restatement -- the reference's real cost, without its
+    virtual calls and mallocs -- in full at C1 and C2, one sweep at C3 (extrapolated to 100)."""
+    from oracle import oracle as orc
+    out = {"kind": "port", "cores": 1, "unit": "s/solve"}
+    t_all = time.perf_counter()
+
+    def lit(sc, sweeps, cfm):
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+        s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+        rhs = np.random.default_rng(0).uniform(-1, 1, 3 * s.m)
+        t0 = time.perf_counter()
+        orc.lit_iterate(s, rhs, cfm, orc.GAUSS_SEIDEL, max_iters=sweeps, tol=0.0)
+        return time.perf_counter() - t0, s.m
+    t, m = lit(scenes.chain(8), 500, 0.0)
+    out["C1_chain8_500_sweeps"] = t
+    t, m = lit(scenes.box_stack(8, 8, 4), 50, 0.01)
+    out["C2_50_sweeps"] = t
+    if budget_s >= 10:
+        t, m = lit(scenes.box_stack(16, 16, 16), 1, 0.01)
+        out["C3_one_sweep"] = t
+        out["C3_100_sweeps_extrapolated"] = 100.0 * t
+    out["sample"] = "oracle/sparse_literal.c (sparse_iterations_utils.cc pair loops), 1 thread, %.1f s in total" % (time.perf_counter() - t_all)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=24, help="independent piles resident per GPU (24 x 1024 columns = two full rounds of 3 tiles per CU)")
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=24, help="C3: independent piles resident per GPU (24 x 1024 columns = two full rounds of 3 tiles per CU)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"], help="the headline workload (`value`)")
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
+    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c2,c4,coupled,c5,literal (1 GPU only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--no-single", action="store_true", help="skip the extra single-pile (latency) measurement")
     args = ap.parse_args()
 
     rank, world, local = egs_dist.env_rank_world()
@@ -180,58 +498,98 @@ def main():
         egs_dist.init_process_group(args.dist_backend)
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
+    legs = set() if (args.legs == "none" or world > 1) else \
+        ({"single_pile", "matvec", "c2", "c4", "coupled", "c5", "literal"} if args.legs == "all" else set(args.legs.split(",")))
 
-    r = run_workload(ctx, args.workload, args.batch, method, args.steps, args.warmup, rank, torch, tdist, world)
+    if args.workload == "c4":     # BASELINE config 4: 1024 ensembles sharded over the ranks
+        seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
+    else:                         # every rank its own piles; seeds differ per rank and pile
+        seeds, scaling, unit = [rank * args.batch + b + 1 for b in range(args.batch)], "weak", "pile-steps/s"
+    r = run_piles(ctx, args.workload, seeds, method, args.steps, args.warmup, torch, tdist, world)
     st, m, sweeps = r["stats"], r["m"], r["sweeps"]
     el, units, citers, resid, failed = egs_dist.reduce_stats(
-        r["elapsed"], args.batch * args.steps, float(m) * sweeps * args.steps, st.residual, st.status != capi.OK,
+        r["elapsed"], len(seeds) * args.steps, float(m) * sweeps * args.steps, st.residual, st.status != capi.OK,
         device=("cuda:%d" % dev) if (world > 1 and args.dist_backend == "nccl") else None)
-    single = None
-    if world == 1 and args.batch != 1 and not args.no_single:
-        single = run_workload(ctx, args.workload, 1, method, args.steps, args.warmup, rank, torch, tdist, world)
 
+    out = None
     if rank == 0:
         nx, ny, nz = r["shape"]
         out = {
             "metric": "constraint_solve_steps_per_sec",
             "value": units / el,
-            "unit": "pile-steps/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": r["prec"],
             "data": "synthetic",
             "config": {
                 "workload": "%s: %dx%dx%d box pile = %d bodies, %d contacts (friction box), projected %s %d sweeps, "
                             "%s; step = assemble + solve + velocity update" % (
-                                args.workload.upper(), nx, ny, nz, nx * ny * nz, m // args.batch,
+                                args.workload.upper(), nx, ny, nz, nx * ny * nz, m // len(seeds),
                                 "Gauss-Seidel" if method == capi.GAUSS_SEIDEL else "SOR(1.5)", sweeps, r["prec"]),
-                "piles_per_gpu": args.batch, "sweeps": sweeps, "cfm": 0.01, "dt": r["dt"], "erp": 0.2,
+                "piles_per_gpu": len(seeds), "piles_total": units // args.steps, "sweeps": sweeps, "cfm": 0.01, "dt": r["dt"], "erp": 0.2,
                 "islands_per_gpu": st.n_islands, "tiles_per_gpu": st.n_tiles,
+                "note": "a BASELINE pile is %d independent columns (SURVEY 8d generator: lateral gap 1e-2); the `coupled` leg is ONE island" % (nx * ny),
                 "schedule": "host plan (islands->tiles, %.1f ms) built once per contact topology, outside the "
                             "timed region" % (r["t_plan"] * 1e3),
-                "parallelism": "piles sharded x%d, no data-path collective" % world,
+                "parallelism": ("ensembles 0..%d sharded over %d ranks (shard_range), no data-path collective" % (C4_ENSEMBLES - 1, world))
+                if args.workload == "c4" else ("piles sharded x%d, no data-path collective" % world),
             },
             "contact_iters_per_sec": citers / el,
             "max_residual": resid,
             "failed": failed,
             "roofline": r["roofline"],
+            "roofline_hbm": r["roofline_hbm"],
         }
-        if single is not None:
-            out["single_pile"] = {
-                "value": args.steps / single["elapsed"], "unit": "pile-steps/s",
-                "ms_per_step": single["elapsed"] / args.steps * 1e3,
-                "contact_iters_per_sec": float(single["m"]) * single["sweeps"] * args.steps / single["elapsed"],
-                "roofline": single["roofline"],
-                "note": "the same workload with ONE pile on the GPU (latency-bound: the dependency chain of a pile)",
-            }
-        if world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1:
+        extra = {}
+        if "matvec" in legs:
+            extra["matvec"] = matvec_leg(ctx, r, args.steps, args.warmup)
+    r["problem"].close()
+    if rank == 0 and world == 1:
+        if "single_pile" in legs and len(seeds) != 1:
+            s1 = run_piles(ctx, args.workload, [1], method, args.steps, args.warmup)
+            extra["single_pile"] = leg_from_run(s1, args.steps, unit, "the headline workload with ONE pile on the GPU: the "
+                                                "dependency chain of a pile (latency); the >= 10x north-star target reads against this")
+            s1["problem"].close()
+        if "c2" in legs and args.workload != "c2":
+            s2 = run_piles(ctx, "c2", [1], method, args.steps, args.warmup)
+            extra["c2"] = leg_from_run(s2, args.steps, "pile-steps/s", "BASELINE config 2: 256-body pile, 1024 contacts, 50 sweeps fp64")
+            s2["problem"].close()
+            if args.cpu_seconds > 0:
+                extra["c2"]["cpu_baseline"] = cpu_baseline("c2", min(3.0, args.cpu_seconds))
+        if "c4" in legs and args.workload != "c4":
+            s4 = run_piles(ctx, "c4", c4_shard_seeds(0, 1), method, args.steps, args.warmup)
+            extra["c4"] = leg_from_run(s4, args.steps, "ensemble-steps/s", "BASELINE config 4 on ONE GPU: 1024 independent 64-body "
+                                       "ensembles, fp32, 50 sweeps, one launch (`--workload c4 --gpus N` shards them)")
+            s4["problem"].close()
+            if args.cpu_seconds > 0:
+                extra["c4"]["cpu_baseline"] = cpu_baseline("c4", min(3.0, args.cpu_seconds))
+        if "coupled" in legs:
+            extra["coupled"] = coupled_leg(ctx, method, max(5, args.steps // 2), 2, min(5.0, args.cpu_seconds))
+        if "c5" in legs:
+            extra["c5"] = c5_leg(ctx, args.cpu_seconds)
+        out.update(extra)
+        if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            cores = os.cpu_count()
+            out["cpu_baseline"]["host_cores_available"] = cores
+            out["cpu_baseline_all_cores"] = {
+                "value": out["cpu_baseline"]["value"] * cores, "unit": out["cpu_baseline"]["unit"], "cores": cores, "kind": "port",
+                "sample": "IDEAL: the 1-thread figure x %d host cores (independent piles, no memory-bandwidth loss assumed); "
+                          "not measured" % cores}
+            out["gpu_over_cpu"] = {"batched_vs_1_core": out["value"] / out["cpu_baseline"]["value"],
+                                   "batched_vs_all_cores_ideal": out["value"] / (out["cpu_baseline"]["value"] * cores)}
+            if "single_pile" in out:
+                out["gpu_over_cpu"]["single_pile_vs_1_core"] = out["single_pile"]["value"] / out["cpu_baseline"]["value"]
+            if "literal" in legs:
+                out["cpu_baseline_literal"] = cpu_literal_baseline(args.cpu_seconds)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -12,10 +12,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeggshell_amd.so")
 
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STALL, ERR_UNSUPPORTED, ERR_LCP_FAILED = range(7)
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STALL, ERR_UNSUPPORTED, ERR_LCP_FAILED, ERR_INTERNAL = range(8)
 JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
 F64, F32 = 0, 1
 JOINT_BALL, CONTACT_BOX = 0, 1
+MV_LOWER, MV_UPPER, MV_DIAG, MV_FULL = 1, 2, 4, 8
+SCHED_QUAD, SCHED_ISO, SCHED_QUAD_PATCHES, SCHED_LANE_PATCHES, SCHED_ALL_GLOBAL = 1, 2, 4, 8, 16
 
 # every symbol include/eggshell_amd.h declares
 EXPORTS = [
@@ -30,6 +32,8 @@ EXPORTS = [
     "egs_update_contacts", "egs_update_contacts_joints", "egs_world_create", "egs_world_destroy", "egs_world_set_bodies",
     "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
     "egs_world_get_lambda", "egs_world_info",
+    "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
+    "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule",
 ]
 
 
@@ -42,7 +46,7 @@ class SolveParams(C.Structure):
 class SolveStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("status", C.c_int32), ("residual", C.c_double),
                 ("n_islands", C.c_int32), ("n_tiles", C.c_int32), ("n_global", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("schedule", C.c_int32), ("tile_constraints", C.c_int32)]
 
 
 class EgsError(RuntimeError):
@@ -140,6 +144,17 @@ class Context:
                                            _p(body1), _p(J0), _p(J1), _p(is_eq), _p(lo), _p(hi), _p(rhs),
                                            C.byref(prm), C.c_int32(precision), _p(x), C.byref(st)))
         return x, st
+
+    def matvec_blocks(self, Minv, body0, body1, J0, J1, x, parts=MV_FULL, eps=0.0, scale=1.0, precision=F64):
+        """sparse::CalculateSparse{JMJtX,Lx,Ux,Dx,...} on flat arrays (one-shot form)."""
+        Minv, J0, J1, x = map(_f64, (Minv, J0, J1, x))
+        body0, body1 = _i32(body0), _i32(body1)
+        n, m = Minv.reshape(-1, 36).shape[0], body0.shape[0]
+        y = np.zeros(3 * m)
+        self.check(load().egs_matvec_blocks(self.h, C.c_int32(n), _p(Minv), C.c_int32(m), _p(body0), _p(body1),
+                                            _p(J0), _p(J1), C.c_int32(parts), C.c_double(eps), C.c_double(scale),
+                                            C.c_int32(precision), _p(x), _p(y)))
+        return y
 
     def update_contacts(self, pos, R, side=None, max_contacts=None, joints=None):
         """Ensemble::UpdateContacts + contact pruning on the GPU (reference order).
@@ -257,6 +272,26 @@ class Problem:
         self.ctx.check(load().egs_problem_get_lambda(self.h, _p(x)))
         return x
 
+    def wres(self):
+        """w = A lambda - rhs of the last solve (the solve kernels' epilogue)."""
+        w = np.zeros(3 * self.m)
+        self.ctx.check(load().egs_problem_get_wres(self.h, _p(w)))
+        return w
+
+    def matvec(self, x=None, parts=MV_FULL, eps=0.0, scale=1.0, fetch=True):
+        """y = part(J M^-1 J^T) x (egs_problem_matvec).  x=None: the device-resident lambda;
+        fetch=False leaves y on the device (asynchronous; matvec_result() reads it)."""
+        xx = _f64(x) if x is not None else None
+        y = np.zeros(3 * self.m) if fetch else None
+        self.ctx.check(load().egs_problem_matvec(self.h, C.c_int32(parts), C.c_double(eps), C.c_double(scale),
+                                                 _p(xx), _p(y)))
+        return y
+
+    def matvec_result(self):
+        y = np.zeros(3 * self.m)
+        self.ctx.check(load().egs_problem_get_matvec(self.h, _p(y)))
+        return y
+
     def accumulators(self):
         a = np.zeros((self.n, 6))
         self.ctx.check(load().egs_problem_get_accumulators(self.h, _p(a)))
@@ -296,6 +331,27 @@ def debug_plan(n_bodies, body0, body1, tile_size=256):
         raise EgsError(st, "egs_debug_plan failed")
     return dict(n_islands=ni.value, n_tiles=nt.value, n_global=ng.value, cons_tile=out[0],
                 pos0=out[1], cnt0=out[2], pos1=out[3], cnt1=out[4])
+
+
+def debug_choose_oversize_schedule(n_patch_tiles, quad_per_cu, patch_per_cu, cu_count=256, patches=True, quad_patches=True):
+    """0 = 4-lane patches, 1 = 1-lane patches, 2 = all-global kernel (host only)."""
+    return int(load().egs_debug_choose_oversize_schedule(C.c_int32(n_patch_tiles), C.c_int32(quad_per_cu),
+                                                         C.c_int32(patch_per_cu), C.c_int32(cu_count),
+                                                         C.c_int32(1 if patches else 0), C.c_int32(1 if quad_patches else 0)))
+
+
+def debug_matvec_plan(n_bodies, body0, body1, tile_size=256):
+    """Host-only view of the mat-vec schedule (tiles, shared bodies, boundary list); needs no GPU."""
+    body0, body1 = _i32(body0), _i32(body1)
+    m = body0.shape[0]
+    vals = [C.c_int32(0) for _ in range(4)]
+    ct = np.full(m, -1, np.int32); cl = np.full(m, -1, np.int32)
+    st = load().egs_debug_matvec_plan(C.c_int32(n_bodies), C.c_int32(m), _p(body0), _p(body1), C.c_int32(tile_size),
+                                      *[C.byref(v) for v in vals], _p(ct), _p(cl))
+    if st != OK:
+        raise EgsError(st, "egs_debug_matvec_plan failed")
+    return dict(n_tiles=vals[0].value, n_islands=vals[1].value, n_shared_bodies=vals[2].value,
+                n_boundary=vals[3].value, cons_tile=ct, cons_lane=cl)
 
 
 def debug_plan_slots(n_bodies, body0, body1, tile_size=256):

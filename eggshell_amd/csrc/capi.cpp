@@ -20,6 +20,7 @@
 #include "collide.h"
 #include "dense_lcp.h"
 #include "kernels.h"
+#include "matvec.h"
 #include "plan.h"
 
 using namespace egs;
@@ -71,13 +72,30 @@ struct egs_context {
 namespace {
 
 constexpr size_t kEventPairs = 4096;
-constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr uint32_t kSpinLimitDefault = 1u << 22;
+// EGS_DEBUG_SPIN_LIMIT=k: bound of the device-side ordering waits (tests force a stall with 1)
+inline uint32_t spin_limit() {
+  const char *e = std::getenv("EGS_DEBUG_SPIN_LIMIT");
+  const long v = e ? std::atol(e) : 0;
+  return v > 0 ? (uint32_t)v : kSpinLimitDefault;
+}
 constexpr int kQuadMaxConstraints = 65536;   // measured crossover: 4 C3 piles on the 4-lane schedule, 6 on the 1-lane one
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
-// Patches wait on each other, so all of a launch's patches must be co-resident:
-// one 1024-thread workgroup (4 lanes per constraint) or two 256-thread workgroups
-// (232 VGPRs) per CU.
-inline int max_quad_patch_tiles(const egs_context *ctx) { return ctx->cu_count; }
+// Which kernel takes the oversize islands of a GS / SOR solve.  Patches wait on each other, so
+// all of a launch's patches must be co-resident: the limits are occupancy (workgroups per CU of
+// the exact kernel instantiation, queried from the runtime) x CUs, never above what was
+// measured on MI355X -- one 1024-thread patch (4 lanes per constraint) or two 256-thread
+// patches (232 VGPRs) per CU.  A kernel change that lowers occupancy lowers the limit and the
+// island falls through to the next schedule instead of stalling.
+enum OversizeSchedule { kQuadPatches = 0, kLanePatches = 1, kAllGlobal = 2 };
+inline OversizeSchedule choose_oversize_schedule(int n_patch_tiles, int quad_per_cu, int patch_per_cu, int cu_count,
+                                                 bool patches_enabled, bool quad_patches_enabled) {
+  if (n_patch_tiles <= 0 || !patches_enabled) return kAllGlobal;
+  const long quad_cap = (long)std::min(quad_per_cu, 1) * cu_count, lane_cap = (long)std::min(patch_per_cu, 2) * cu_count;
+  if (quad_patches_enabled && n_patch_tiles <= quad_cap) return kQuadPatches;
+  if (n_patch_tiles <= lane_cap) return kLanePatches;
+  return kAllGlobal;
+}
 
 // Isotropic bodies, batched work: the register-light tile kernel (no stored B, three
 // 256-constraint tiles per CU in fp64, four in fp32) against the regular one (fp64:
@@ -93,7 +111,6 @@ inline bool iso_schedule_pays(long m, int cu, int precision) {
   const double regular = 0.53 * ((t / 2 + cu - 1) / cu);
   return iso < regular;
 }
-inline int max_patch_tiles(const egs_context *ctx) { return 2 * ctx->cu_count; }
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -165,8 +182,12 @@ struct egs_problem {
   // used for GS/SOR when the problem is small and every island fits a tile
   Plan planq;
   bool use_quad = false;
-  bool patch_enabled = true;   // EGS_PATCH=0 forces the all-global path for oversize islands
-  bool quad_patch = false;     // patches run on the 4-lanes-per-constraint kernel (EGS_QUAD_PATCH=0: 1 lane)
+  // which kernel takes the oversize islands of a GS / SOR solve (choose_oversize_schedule; EGS_PATCH=0
+  // forces the all-global kernel, EGS_QUAD_PATCH=0 the 1-lane patches) and how many workgroups the
+  // all-global kernel's persistent grid may have: both from the runtime's occupancy of the kernels
+  int last_iso = 0;            // the last tile launch used the isotropic-body variant
+  int oversize = 2;            // OversizeSchedule
+  int global_max_blocks = 1;
   DevBuf<LaneDesc> q_lanes;
   DevBuf<int32_t> q_tile_nslots, q_tile_slot_off, q_slot_body;
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
@@ -184,13 +205,26 @@ struct egs_problem {
   DevBuf<unsigned char> Minv_r, J0, J1, lo, hi, rhs, x, acc, wres;
   DevBuf<unsigned char> gB0, gB1, gD, gden, gdx;  // cross-workgroup workspace
   DevBuf<uint8_t> is_eq;
+  // [0]: device-side ordering wait timed out (EGS_ERR_STALL).  STICKY: the solve kernels OR into
+  // it and only reporting it clears it, so a stall in any step of an asynchronous run is seen.
+  // [1]: scratch word of the isotropy check.
   DevBuf<int32_t> error_flag;
+  int32_t *h_flag = nullptr;   // page-locked copy of [0], refreshed by an async copy after every solve
   // per-sweep history of a chunk of sweeps (tolerance-terminated solves, see kernels.h)
   DevBuf<unsigned char> hist_x, hist_acc;
   DevBuf<double> hist_out;
   int hist_sweeps = 0;        // 0: off for the next launch; k: record k sweeps
   bool residual_pending = false;   // wres/x hold a finished solve whose residual sums were not reduced yet
   bool have_blocks = false, have_state = false, have_constraints = false, minv_r_valid = false;
+  // stand-alone mat-vec (matvec_plan.h): schedule built at the first product after a topology change
+  MatvecPlan mvplan;
+  bool mv_ready = false;
+  DevBuf<MvLane> mv_lanes;
+  DevBuf<MvTile> mv_tiles;
+  DevBuf<MvSlot> mv_slots;
+  DevBuf<uint16_t> mv_ents;
+  DevBuf<MvBoundary> mv_boundary;
+  DevBuf<unsigned char> mv_T, mv_x, mv_y;
   bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
   size_t real_size() const { return precision == EGS_F32 ? sizeof(float) : sizeof(double); }
@@ -212,9 +246,9 @@ egs_status guarded(egs_context *ctx, F &&f) {
   } catch (const std::invalid_argument &e) {
     return fail(ctx, EGS_ERR_INVALID, e.what());
   } catch (const std::bad_alloc &) {
-    return fail(ctx, EGS_ERR_HIP, "host allocation failed");
-  } catch (const std::exception &e) {
-    return fail(ctx, EGS_ERR_HIP, e.what());
+    return fail(ctx, EGS_ERR_INTERNAL, "host allocation failed");
+  } catch (const std::exception &e) {   // std::logic_error from the planner etc.: a library bug, not a HIP failure
+    return fail(ctx, EGS_ERR_INTERNAL, e.what());
   }
 }
 
@@ -259,17 +293,36 @@ void ensure_minv_real(egs_problem *p) {
   if (p->n > 0 && !(ie && std::atoi(ie) == 0)) {
     hipStream_t s = p->ctx->stream;
     int one = 1, flag = 0;
-    HIPCHK(hipMemcpyAsync(p->error_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, s));
-    if (p->precision == EGS_F32) launch_minv_iso<float>(p->n, reinterpret_cast<const float *>(p->Minv_r.p), p->error_flag.p, s);
-    else launch_minv_iso<double>(p->n, reinterpret_cast<const double *>(p->Minv_r.p), p->error_flag.p, s);
-    HIPCHK(hipMemcpyAsync(&flag, p->error_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int), s));
+    int32_t *scratch = p->error_flag.p + 1;
+    HIPCHK(hipMemcpyAsync(scratch, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    if (p->precision == EGS_F32) launch_minv_iso<float>(p->n, reinterpret_cast<const float *>(p->Minv_r.p), scratch, s);
+    else launch_minv_iso<double>(p->n, reinterpret_cast<const double *>(p->Minv_r.p), scratch, s);
+    HIPCHK(hipMemcpyAsync(&flag, scratch, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const bool iso = flag != 0;
     if (iso != p->minv_iso) p->tile_plan_ready = false;   // the preferred tile size depends on it
     p->minv_iso = iso;
   }
 }
+
+// ---- the sticky stall flag ---------------------------------------------------
+// asynchronous refresh of the page-locked copy (4 bytes), enqueued behind a solve
+void post_flag_copy(egs_problem *p) {
+  HIPCHK(hipMemcpyAsync(p->h_flag, p->error_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
+}
+// A stall was seen: clear it (it is being reported now) and fail.  Synchronises.
+egs_status report_stall(egs_problem *p) {
+  hipStream_t s = p->ctx->stream;
+  HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
+  HIPCHK(hipStreamSynchronize(s));
+  *p->h_flag = 0;
+  p->ctx->error = "device ordering wait timed out";
+  return EGS_ERR_STALL;
+}
+// Non-blocking look at the page-locked copy: true once the copy behind a stalled solve has
+// landed.  Entry points that enqueue more work call it first; entry points that have just
+// synchronised see every earlier solve.
+inline bool stall_seen(const egs_problem *p) { return p->h_flag && *static_cast<volatile int32_t *>(p->h_flag) != 0; }
 
 void record_kernel_event(egs_context *ctx, bool begin) {
   if (ctx->kev.empty()) return;
@@ -285,8 +338,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
   egs_context *ctx = p->ctx;
   const bool quad = p->use_quad && method != EGS_JACOBI;
   if (!quad) ensure_tile_plan(p);
-  const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 &&
-                     p->plan.n_patch_tiles <= max_patch_tiles(ctx) && p->patch_enabled;
+  const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 && p->oversize != kAllGlobal;
   record_kernel_event(ctx, true);
   // oversize islands accumulate in global memory (all bodies on the all-global kernel, shared
   // bodies of patches): from zero, unless this launch continues the previous one
@@ -317,7 +369,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.sweeps = sweeps;
     a.resume = resume;
     a.max_slots = quad ? p->planq.max_slots : p->plan.max_slots;
-    a.spin_limit = kSpinLimit;
+    a.spin_limit = spin_limit();
     a.iso = (p->minv_iso && !quad && p->plan.block == 256 && iso_schedule_pays(p->m, ctx->cu_count, p->precision)) ? 1 : 0;
     a.n_bodies = p->n;
     if (p->hist_sweeps > 0) {   // the isotropic variant has no registers to spare for it
@@ -329,6 +381,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       const char *ie = std::getenv("EGS_ISO");   // 2: force the variant wherever the bodies allow it (experiments)
       if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256 && p->hist_sweeps == 0) a.iso = 1;
     }
+    p->last_iso = quad ? 0 : a.iso;
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
       launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
@@ -353,14 +406,14 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.wres = reinterpret_cast<REAL *>(p->wres.p);
     a.error_flag = p->error_flag.p;
     a.cfm = cfm; a.kscale = kscale; a.sweeps = sweeps; a.resume = resume;
-    a.max_slots = p->plan.patch_max_slots; a.spin_limit = kSpinLimit;
+    a.max_slots = p->plan.patch_max_slots; a.spin_limit = spin_limit();
     HIPCHK(hipMemsetAsync(p->gtickets.p, 0, sizeof(uint32_t) * (size_t)(p->n > 0 ? p->n : 1), ctx->stream));
     a.n_bodies = p->n;
     if (p->hist_sweeps > 0) {
       a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
       a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
     }
-    if (p->quad_patch && p->plan.n_patch_tiles <= max_quad_patch_tiles(ctx)) {
+    if (p->oversize == kQuadPatches) {
       // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
       a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
@@ -398,13 +451,13 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     g.sweeps = sweeps;
     g.resume = resume;
     g.method = method;
-    g.spin_limit = kSpinLimit;
+    g.spin_limit = spin_limit();
     g.m = p->m;
     if (p->hist_sweeps > 0 && method != EGS_JACOBI) {
       g.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
       g.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
     }
-    launch_global_solve<REAL>(g, ctx->stream);
+    launch_global_solve<REAL>(g, p->global_max_blocks, ctx->stream);
   }
   record_kernel_event(ctx, false);
   HIPCHK(hipGetLastError());
@@ -445,6 +498,11 @@ double read_residual(egs_problem *p, int *err_flag) {
   double sum[4] = {0, 0, 0, 0};
   for (int b = 0; b < kResidualBlocks; ++b)
     for (int k = 0; k < 4; ++k) sum[k] += part[4 * b + k];
+  if (flag) {   // reported to the caller now: clear the sticky word
+    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
+    HIPCHK(hipStreamSynchronize(s));
+    *p->h_flag = 0;
+  }
   if (err_flag) *err_flag = flag;
   return std::sqrt(sum[0]) + (std::sqrt(sum[1]) + std::sqrt(sum[2]) + std::sqrt(sum[3]));
 }
@@ -465,6 +523,10 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_tiles = pl.n_tiles;
   st->n_global = (int32_t)pl.global.size();
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
+  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0);
+  if (!p->use_quad && !pl.global.empty())
+    st->schedule |= p->oversize == kQuadPatches ? EGS_SCHED_QUAD_PATCHES : p->oversize == kLanePatches ? EGS_SCHED_LANE_PATCHES : EGS_SCHED_ALL_GLOBAL;
+  st->tile_constraints = pl.block;
 }
 
 template <typename REAL>
@@ -491,7 +553,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   }
   ensure_minv_real(p);   // also decides the isotropic fast path, hence the tile size
   if (!p->use_quad || prm->method == EGS_JACOBI) ensure_tile_plan(p);
-  HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream));
+  if (stall_seen(p)) return report_stall(p);   // an earlier asynchronous solve timed out
   if (!(prm->tol > 0)) {
     // tickets are 32-bit counters that advance by cnt per sweep: very long runs
     // are cut into resumed launches so they cannot wrap
@@ -504,6 +566,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     } while (done < prm->max_iters);
     p->last_iterations = prm->max_iters;
     p->residual_pending = !stats;   // nobody is looking: the reduction runs when egs_problem_get_stats asks
+    if (!stats) post_flag_copy(p);  // ... and a stall shows up at the next call or the next synchronising getter
     if (stats) {
       int flag = 0;
       launch_residual(p);
@@ -564,7 +627,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
       HIPCHK(hipMemcpyAsync(&f32, p->error_flag.p, sizeof f32, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       flag = f32;
-      if (flag) break;
+      if (flag) { HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream)); break; }
       int stop = 0;   // first recorded sweep (1-based) at which the reference would stop
       double err_stop = 0, err_last = err;
       for (int sw = 1; sw <= chunk; ++sw) {
@@ -647,6 +710,87 @@ void do_velocity(egs_problem *p, double dt) {
   HIPCHK(hipGetLastError());
 }
 
+
+// The schedule of the stand-alone products (matvec_plan.h), built on first use.
+void ensure_matvec_plan(egs_problem *p) {
+  if (p->mv_ready) return;
+  const char *te = std::getenv("EGS_MV_TILE");   // experiment knob: 128 / 256 constraints per tile
+  const int forced = te ? std::atoi(te) : 0;
+  p->mvplan = build_matvec_plan(p->n, p->m, p->h_body0.data(), p->h_body1.data(), forced == 128 ? 128 : 256);
+  const MatvecPlan &pl = p->mvplan;
+  stage(p->ctx, p->mv_lanes, pl.lanes);
+  stage(p->ctx, p->mv_tiles, pl.tiles);
+  stage(p->ctx, p->mv_slots, pl.slots);
+  stage(p->ctx, p->mv_ents, pl.ents);
+  stage(p->ctx, p->mv_boundary, pl.boundary);
+  const size_t rs = p->real_size(), mm = (size_t)(p->m > 0 ? p->m : 1);
+  p->mv_T.alloc((size_t)(pl.n_shared_entries > 0 ? pl.n_shared_entries : 1) * 6 * rs);
+  p->mv_x.alloc(mm * 3 * rs);
+  p->mv_y.alloc(mm * 3 * rs);
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  p->mv_ready = true;
+}
+
+template <typename REAL>
+void launch_matvec_t(egs_problem *p, int parts, REAL eps, REAL scale, const REAL *x) {
+  const MatvecPlan &pl = p->mvplan;
+  MatvecArgs<REAL> a;
+  a.lanes = p->mv_lanes.p; a.tiles = p->mv_tiles.p; a.slots = p->mv_slots.p; a.ents = p->mv_ents.p;
+  a.boundary = p->mv_boundary.p; a.n_boundary = (int32_t)pl.boundary.size();
+  a.max_slots = pl.max_slots;
+  a.Minv = reinterpret_cast<const REAL *>(p->Minv_r.p);
+  a.J0 = reinterpret_cast<const REAL *>(p->J0.p); a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
+  a.x = x; a.y = reinterpret_cast<REAL *>(p->mv_y.p); a.T = reinterpret_cast<REAL *>(p->mv_T.p);
+  a.eps = eps; a.scale = scale; a.accumulate = 0;
+  record_kernel_event(p->ctx, true);
+  if (parts == EGS_MV_FULL) {
+    launch_matvec<REAL>(a, 8, pl.n_tiles, pl.block, p->ctx->stream);
+  } else {   // Lx + Ux, Ux + Dx, Lx + Dx as the reference adds them (sparse_iterations_utils.cc:563-569, 606-622)
+    for (int bit = 1; bit <= 4; bit <<= 1) {
+      if (!(parts & bit)) continue;
+      launch_matvec<REAL>(a, bit, pl.n_tiles, pl.block, p->ctx->stream);
+      a.accumulate = 1;
+    }
+  }
+  record_kernel_event(p->ctx, false);
+  HIPCHK(hipGetLastError());
+}
+
+egs_status do_matvec(egs_problem *p, int32_t parts, double eps, double scale, const double *x, double *y) {
+  egs_context *ctx = p->ctx;
+  if (!(parts == EGS_MV_FULL || (parts >= 1 && parts <= 7)))
+    return fail(ctx, EGS_ERR_INVALID, "parts must be EGS_MV_FULL or a combination of LOWER / UPPER / DIAG");
+  if (!p->have_blocks) return fail(ctx, EGS_ERR_INVALID, "no system uploaded (set_blocks or assemble first)");
+  if (p->m == 0) return EGS_OK;
+  ensure_minv_real(p);
+  ensure_matvec_plan(p);
+  if (x) upload_real(p, p->mv_x, x, (size_t)p->m * 3);
+  // x = NULL: the device-resident lambda of the last solve
+  if (p->precision == EGS_F32)
+    launch_matvec_t<float>(p, parts, (float)eps, (float)scale, reinterpret_cast<const float *>(x ? p->mv_x.p : p->x.p));
+  else
+    launch_matvec_t<double>(p, parts, eps, scale, reinterpret_cast<const double *>(x ? p->mv_x.p : p->x.p));
+  if (y) download_real(p, p->mv_y, y, (size_t)p->m * 3);
+  return EGS_OK;
+}
+
+// egs_solve_blocks / egs_matvec_blocks are stateless for their caller; the context keeps the
+// last problem (schedule + device buffers) and reuses it while the constraint graph is unchanged.
+egs_status oneshot_problem(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0, const int32_t *body1,
+                           int32_t precision, egs_problem **out) {
+  egs_problem *p = ctx->oneshot;
+  const bool reuse = p && p->n == n && p->m == m && p->precision == precision &&
+                     (m == 0 || (std::memcmp(p->h_body0.data(), body0, (size_t)m * sizeof(int32_t)) == 0 &&
+                                 std::memcmp(p->h_body1.data(), body1, (size_t)m * sizeof(int32_t)) == 0));
+  if (!reuse) {
+    if (p) { egs_problem_destroy(p); ctx->oneshot = nullptr; }
+    egs_status st = egs_problem_create(ctx, n, m, body0, body1, precision, &p);
+    if (st != EGS_OK) return st;
+    ctx->oneshot = p;
+  }
+  *out = p;
+  return EGS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -780,11 +924,18 @@ void ensure_tile_plan(egs_problem *p) {
     stage(p->ctx, p->p_tile_nslots, pl.patch_tile_nslots);
     stage(p->ctx, p->p_tile_slot_off, pl.patch_tile_slot_off);
     stage(p->ctx, p->p_slot_body, pl.patch_slot_body);
-    const char *pe = std::getenv("EGS_PATCH");
-    p->patch_enabled = !(pe && std::atoi(pe) == 0);
-    const char *qp = std::getenv("EGS_QUAD_PATCH");
-    p->quad_patch = pl.block == 256 && pl.n_patch_tiles <= max_quad_patch_tiles(p->ctx) && !(qp && std::atoi(qp) == 0);
-    if (p->quad_patch) {
+  }
+  {
+    const char *pe = std::getenv("EGS_PATCH"), *qp = std::getenv("EGS_QUAD_PATCH");
+    const bool f32 = p->precision == EGS_F32;
+    const size_t lds = (size_t)pl.patch_max_slots * (6 * p->real_size() + sizeof(unsigned));
+    const int occ_quad = pl.n_patch_tiles > 0 ? (f32 ? occupancy_quad_patch_solve<float>(lds) : occupancy_quad_patch_solve<double>(lds)) : 0;
+    const int occ_lane = pl.n_patch_tiles > 0 ? (f32 ? occupancy_patch_solve<float>(lds) : occupancy_patch_solve<double>(lds)) : 0;
+    const int occ_glob = pl.global.empty() ? 1 : (f32 ? occupancy_global_solve<float>() : occupancy_global_solve<double>());
+    p->oversize = choose_oversize_schedule(pl.n_patch_tiles, occ_quad, occ_lane, p->ctx->cu_count, !(pe && std::atoi(pe) == 0),
+                                           pl.block == 256 && !(qp && std::atoi(qp) == 0));
+    p->global_max_blocks = std::max(1, std::min(occ_glob, 1) * p->ctx->cu_count);
+    if (p->oversize == kQuadPatches) {
       const size_t rsz = p->real_size(), mm2 = (size_t)m;
       p->wsB0.alloc(mm2 * 18 * rsz); p->wsB1.alloc(mm2 * 18 * rsz); p->wsD.alloc(mm2 * 9 * rsz); p->wsInv.alloc(mm2 * 3 * rsz);
     }
@@ -808,6 +959,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   p->h_body0.assign(body0, body0 + m);
   p->h_body1.assign(body1, body1 + m);
   p->tile_plan_ready = false;
+  p->mv_ready = false;
   p->use_quad = false;
   p->have_blocks = false;
   p->have_constraints = false;
@@ -847,7 +999,6 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
     HIPCHK(hipMemsetAsync(p->x.p, 0, mm * 3 * rs, s));
     HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
   }
-  HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), s));
   HIPCHK(hipStreamSynchronize(s));
   // the 1-lane schedule is built at the first solve that needs it (ensure_tile_plan):
   // its tile size depends on the mass blocks, which arrive after the topology
@@ -885,11 +1036,14 @@ egs_status egs_problem_create(egs_context *ctx, int32_t n, int32_t m, const int3
     p->res_partials.alloc(4 * kResidualBlocks);
     p->Minv_r.alloc(nn * 36 * rs);
     p->acc.alloc(nn * 6 * rs);
-    p->error_flag.alloc(1);
+    p->error_flag.alloc(2);
+    HIPCHK(hipMemsetAsync(p->error_flag.p, 0, 2 * sizeof(int32_t), ctx->stream));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->h_flag), 64, hipHostMallocDefault));
+    *p->h_flag = 0;
     problem_set_topology(p, m, body0, body1);
     return EGS_OK;
   });
-  if (st != EGS_OK) { delete p; return st; }
+  if (st != EGS_OK) { if (p->h_flag) (void)hipHostFree(p->h_flag); delete p; return st; }
   *out = p;
   return EGS_OK;
 }
@@ -936,6 +1090,7 @@ egs_status egs_problem_create_batch(egs_context *ctx, int32_t n_ensembles, const
 void egs_problem_destroy(egs_problem *p) {
   if (!p) return;
   if (p->ctx && p->ctx->stream) (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->h_flag) (void)hipHostFree(p->h_flag);
   delete p;
 }
 
@@ -963,12 +1118,18 @@ egs_status egs_problem_solve(egs_problem *p, const egs_solve_params *params, egs
 
 egs_status egs_problem_get_lambda(egs_problem *p, double *x) {
   if (!p || !x) return EGS_ERR_INVALID;
-  return guarded(p->ctx, [&]() -> egs_status { download_real(p, p->x, x, (size_t)p->m * 3); return EGS_OK; });
+  return guarded(p->ctx, [&]() -> egs_status {
+    download_real(p, p->x, x, (size_t)p->m * 3);
+    return stall_seen(p) ? report_stall(p) : EGS_OK;   // the download synchronised: every earlier solve is accounted for
+  });
 }
 
 egs_status egs_problem_get_accumulators(egs_problem *p, double *a) {
   if (!p || !a) return EGS_ERR_INVALID;
-  return guarded(p->ctx, [&]() -> egs_status { download_real(p, p->acc, a, (size_t)p->n * 6); return EGS_OK; });
+  return guarded(p->ctx, [&]() -> egs_status {
+    download_real(p, p->acc, a, (size_t)p->n * 6);
+    return stall_seen(p) ? report_stall(p) : EGS_OK;
+  });
 }
 
 egs_status egs_problem_set_state(egs_problem *p, const double *pos, const double *R, const double *v,
@@ -1032,6 +1193,7 @@ egs_status egs_problem_step(egs_problem *p, double dt, double erp, const egs_sol
   if (!p->have_state || !p->have_constraints) return fail(p->ctx, EGS_ERR_INVALID, "set_state and set_constraints first");
   if (!(dt > 0)) return fail(p->ctx, EGS_ERR_INVALID, "dt must be > 0");
   return guarded(p->ctx, [&]() -> egs_status {
+    if (stall_seen(p)) return report_stall(p);   // an earlier (asynchronous) step timed out
     do_assemble(p, dt, erp);
     egs_status st = do_solve(p, params, stats);
     if (st != EGS_OK) return st;
@@ -1063,7 +1225,7 @@ egs_status egs_problem_get_velocity(egs_problem *p, double *v6) {
   return guarded(p->ctx, [&]() -> egs_status {
     if (p->n) HIPCHK(hipMemcpyAsync(v6, p->v6.p, (size_t)p->n * 6 * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
-    return EGS_OK;
+    return stall_seen(p) ? report_stall(p) : EGS_OK;
   });
 }
 
@@ -1071,6 +1233,7 @@ egs_status egs_problem_advance(egs_problem *p, double dt) {
   if (!p) return EGS_ERR_INVALID;
   if (!p->have_state) return fail(p->ctx, EGS_ERR_INVALID, "set_state and step first");
   return guarded(p->ctx, [&]() -> egs_status {
+    if (stall_seen(p)) return report_stall(p);   // do not integrate a lambda that came out of a timed-out wait
     launch_advance(p->n, p->pos.p, p->R.p, p->v.p, p->w.p, p->v6.p, dt, p->ctx->stream);
     HIPCHK(hipGetLastError());
     return EGS_OK;
@@ -1087,7 +1250,7 @@ egs_status egs_problem_get_state(egs_problem *p, double *pos, double *R, double 
     if (v && n) HIPCHK(hipMemcpyAsync(v, p->v.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (w && n) HIPCHK(hipMemcpyAsync(w, p->w.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    return EGS_OK;
+    return stall_seen(p) ? report_stall(p) : EGS_OK;
   });
 }
 
@@ -1113,22 +1276,78 @@ egs_status egs_solve_blocks(egs_context *ctx, int32_t n, const double *Minv, int
   if (!ctx) return EGS_ERR_INVALID;
   if (m > 0 && (!Minv || !body0 || !body1 || !J0 || !J1 || !is_eq || !lo || !hi || !rhs || !x))
     return fail(ctx, EGS_ERR_INVALID, "NULL array");
-  egs_problem *p = ctx->oneshot;
-  const bool reuse = p && p->n == n && p->m == m && p->precision == precision &&
-                     (m == 0 || (std::memcmp(p->h_body0.data(), body0, (size_t)m * sizeof(int32_t)) == 0 &&
-                                 std::memcmp(p->h_body1.data(), body1, (size_t)m * sizeof(int32_t)) == 0));
-  egs_status st = EGS_OK;
-  if (!reuse) {
-    if (p) { egs_problem_destroy(p); ctx->oneshot = nullptr; }
-    st = egs_problem_create(ctx, n, m, body0, body1, precision, &p);
-    if (st != EGS_OK) return st;
-    ctx->oneshot = p;
-  }
+  egs_problem *p = nullptr;
+  egs_status st = oneshot_problem(ctx, n, m, body0, body1, precision, &p);
+  if (st != EGS_OK) return st;
   st = egs_problem_set_blocks(p, Minv, J0, J1, is_eq, lo, hi, rhs);
   egs_solve_stats local;
   if (st == EGS_OK) st = egs_problem_solve(p, params, stats ? stats : &local);
   if (st == EGS_OK && m > 0) st = egs_problem_get_lambda(p, x);
   return st;
+}
+
+egs_status egs_problem_matvec(egs_problem *p, int32_t parts, double eps, double scale, const double *x, double *y) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status { return do_matvec(p, parts, eps, scale, x, y); });
+}
+
+egs_status egs_problem_get_matvec(egs_problem *p, double *y) {
+  if (!p || !y) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    if (!p->mv_ready) return fail(p->ctx, EGS_ERR_INVALID, "egs_problem_matvec first");
+    download_real(p, p->mv_y, y, (size_t)p->m * 3);
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_get_wres(egs_problem *p, double *w) {
+  if (!p || !w) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    download_real(p, p->wres, w, (size_t)p->m * 3);
+    return stall_seen(p) ? report_stall(p) : EGS_OK;
+  });
+}
+
+egs_status egs_matvec_blocks(egs_context *ctx, int32_t n, const double *Minv, int32_t m, const int32_t *body0,
+                             const int32_t *body1, const double *J0, const double *J1, int32_t parts, double eps,
+                             double scale, int32_t precision, const double *x, double *y) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (m > 0 && (!Minv || !body0 || !body1 || !J0 || !J1 || !x || !y)) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  egs_problem *p = nullptr;
+  egs_status st = oneshot_problem(ctx, n, m, body0, body1, precision, &p);
+  if (st != EGS_OK) return st;
+  st = egs_problem_set_blocks(p, Minv, J0, J1, nullptr, nullptr, nullptr, nullptr);
+  if (st == EGS_OK) st = egs_problem_matvec(p, parts, eps, scale, x, y);
+  return st;
+}
+
+int32_t egs_debug_choose_oversize_schedule(int32_t n_patch_tiles, int32_t quad_per_cu, int32_t patch_per_cu,
+                                           int32_t cu_count, int32_t patches_enabled, int32_t quad_patches_enabled) {
+  return (int32_t)choose_oversize_schedule(n_patch_tiles, quad_per_cu, patch_per_cu, cu_count, patches_enabled != 0,
+                                           quad_patches_enabled != 0);
+}
+
+egs_status egs_debug_matvec_plan(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,
+                                 int32_t *n_tiles, int32_t *n_islands, int32_t *n_shared_bodies, int32_t *n_boundary,
+                                 int32_t *cons_tile, int32_t *cons_lane) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
+  try {
+    const MatvecPlan pl = build_matvec_plan(n, m, body0, body1, tile_size);
+    if (n_tiles) *n_tiles = pl.n_tiles;
+    if (n_islands) *n_islands = pl.n_islands;
+    if (n_shared_bodies) *n_shared_bodies = pl.n_shared_bodies;
+    if (n_boundary) *n_boundary = (int32_t)pl.boundary.size();
+    for (int t = 0; t < pl.n_tiles; ++t)
+      for (int l = 0; l < pl.block; ++l) {
+        const MvLane &d = pl.lanes[(size_t)t * pl.block + l];
+        if (d.cidx < 0) continue;
+        if (cons_tile) cons_tile[d.cidx] = t;
+        if (cons_lane) cons_lane[d.cidx] = l;
+      }
+    return EGS_OK;
+  } catch (const std::exception &) {
+    return EGS_ERR_INVALID;
+  }
 }
 
 egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double *A, const double *b,
@@ -1422,6 +1641,10 @@ egs_status egs_world_step(egs_world *w, double dt, double erp, const egs_solve_p
       do_assemble(p, dt, erp);
       egs_status st = do_solve(p, params, stats);
       if (st != EGS_OK) return st;
+      // the body state must not be advanced with a lambda that came out of a timed-out ordering
+      // wait: look at the flag before integrating (one 4-byte read-back per step)
+      HIPCHK(hipStreamSynchronize(s));
+      if (stall_seen(p)) return report_stall(p);
     } else {  // no constraints: v_dot = M^-1 f (ensembles.cc:504-505)
       if (egs_status st = validate_params(w->ctx, params)) return st;
       HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * p->real_size(), s));

@@ -81,8 +81,15 @@ void launch_mass_times_force(int n, const double *Minv, const double *f_ext, dou
 template <typename REAL>
 void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
+// max_blocks: how many workgroups of the persistent grid may be launched (all must be resident)
 template <typename REAL>
-void launch_global_solve(const GlobalArgs<REAL> &a, hipStream_t s);
+void launch_global_solve(const GlobalArgs<REAL> &a, int max_blocks, hipStream_t s);
+// workgroups per CU the hardware keeps resident for the cross-workgroup kernels' exact
+// instantiations (hipOccupancyMaxActiveBlocksPerMultiprocessor, the smallest over method /
+// history variants); 0 if the query fails
+template <typename REAL> int occupancy_global_solve();
+template <typename REAL> int occupancy_patch_solve(size_t lds_bytes);
+template <typename REAL> int occupancy_quad_patch_solve(size_t lds_bytes);
 // w = A x - rhs for the constraints of a GlobalDesc list (after the last sweep)
 template <typename REAL>
 void launch_global_wres(const GlobalArgs<REAL> &a, hipStream_t s);

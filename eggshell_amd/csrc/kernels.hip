@@ -878,11 +878,24 @@ void launch_minv_iso(int n, const REAL *W, int *flag, hipStream_t s) {
 
 
 template <typename REAL>
-void launch_global_solve(const GlobalArgs<REAL> &a0, hipStream_t s) {
+int occupancy_global_solve() {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, global_solve_kernel<REAL, 1>, 256, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, global_solve_kernel<REAL, 2>, 256, 0) != hipSuccess) return 0;
+  return a < b ? a : b;
+}
+template int occupancy_global_solve<double>();
+template int occupancy_global_solve<float>();
+
+template <typename REAL>
+void launch_global_solve(const GlobalArgs<REAL> &a0, int max_blocks, hipStream_t s) {
   if (a0.mg <= 0) return;
   GlobalArgs<REAL> a = a0;
   const int flat_blocks = (a.mg + 255) / 256;
-  const int grid = flat_blocks < 256 ? flat_blocks : 256;  // <= 1 workgroup per CU: all resident
+  // the persistent grid's workgroups wait on each other: never more than are resident together
+  // (max_blocks = occupancy x CUs, capped at one per CU; the lanes take more constraints each instead)
+  const int cap = max_blocks > 0 ? max_blocks : 1;
+  const int grid = flat_blocks < cap ? flat_blocks : cap;
   a.per_lane = (a.mg + grid * 256 - 1) / (grid * 256);
   const size_t tick_bytes = sizeof(uint32_t) * (size_t)(a.n_bodies > 0 ? a.n_bodies : 1);
   hipLaunchKernelGGL((global_prepare_kernel<REAL>), dim3(flat_blocks), dim3(256), 0, s, a);
@@ -921,7 +934,7 @@ void launch_cons_prepare(const SolveArgs<REAL> &a, hipStream_t s) {
 
 #define EGS_INSTANTIATE(REAL)                                                                                \
   template void launch_tile_solve<REAL>(const SolveArgs<REAL> &, int, int, int, hipStream_t);                \
-  template void launch_global_solve<REAL>(const GlobalArgs<REAL> &, hipStream_t);                            \
+  template void launch_global_solve<REAL>(const GlobalArgs<REAL> &, int, hipStream_t);                            \
   template void launch_cons_prepare<REAL>(const SolveArgs<REAL> &, hipStream_t);                             \
   template void launch_global_wres<REAL>(const GlobalArgs<REAL> &, hipStream_t);                            \
   template void launch_assemble<REAL>(const AssembleArgs &, hipStream_t);                                    \

@@ -178,6 +178,21 @@ void launch_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, uint3
   else hipLaunchKernelGGL((patch_solve_kernel<REAL, 2, false>), dim3(n_tiles), dim3(256), lds, s, a, tickets);
 }
 
+// Workgroups of this kernel one CU keeps resident (the smallest over its instantiations):
+// patches wait on each other, so a launch must not have more patches than that times the CUs.
+template <typename REAL>
+int occupancy_patch_solve(size_t lds) {
+  int best = 1 << 30, nb = 0;
+#define EGS_OCC(M, H)                                                                                              \
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, patch_solve_kernel<REAL, M, H>, 256, lds) != hipSuccess) return 0; \
+  best = nb < best ? nb : best;
+  EGS_OCC(1, true) EGS_OCC(1, false) EGS_OCC(2, true) EGS_OCC(2, false)
+#undef EGS_OCC
+  return best;
+}
+template int occupancy_patch_solve<double>(size_t);
+template int occupancy_patch_solve<float>(size_t);
+
 template void launch_patch_solve<double>(const SolveArgs<double> &, int, int, uint32_t *, hipStream_t);
 template void launch_patch_solve<float>(const SolveArgs<float> &, int, int, uint32_t *, hipStream_t);
 

@@ -391,6 +391,19 @@ void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, 
   }
 }
 
+template <typename REAL>
+int occupancy_quad_patch_solve(size_t lds) {
+  int best = 1 << 30, nb = 0;
+#define EGS_OCC(M, H)                                                                                     \
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, quad_solve_kernel<REAL, M, 256, true, H>, 1024, lds) != hipSuccess) return 0; \
+  best = nb < best ? nb : best;
+  EGS_OCC(1, true) EGS_OCC(1, false) EGS_OCC(2, true) EGS_OCC(2, false)
+#undef EGS_OCC
+  return best;
+}
+template int occupancy_quad_patch_solve<double>(size_t);
+template int occupancy_quad_patch_solve<float>(size_t);
+
 template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
 template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, int, hipStream_t);
 template void launch_quad_patch_solve<double>(const SolveArgs<double> &, int, int, uint32_t *, hipStream_t);

@@ -39,9 +39,15 @@ typedef enum {
   EGS_ERR_INVALID = 1,     /* bad argument (the reference would CHECK/Panic) */
   EGS_ERR_NO_DEVICE = 2,   /* no gfx950 device / HIP runtime unusable */
   EGS_ERR_HIP = 3,         /* a HIP call failed */
-  EGS_ERR_STALL = 4,       /* device-side ordering wait timed out (bug guard) */
+  EGS_ERR_STALL = 4,       /* device-side ordering wait timed out (bug guard).  The device flag is
+                              sticky: a stall in an asynchronous call (step / solve without stats)
+                              is returned by the next call on the problem that enqueues work once
+                              the flag has landed, and at the latest by the next call that
+                              synchronises (get_lambda / get_velocity / get_state / get_stats ...);
+                              reporting clears it.  egs_world_step checks before it integrates. */
   EGS_ERR_UNSUPPORTED = 5, /* feature not built yet */
-  EGS_ERR_LCP_FAILED = 6   /* dense LCP did not reach a solution (lcp.cc:250) */
+  EGS_ERR_LCP_FAILED = 6,  /* dense LCP did not reach a solution (lcp.cc:250) */
+  EGS_ERR_INTERNAL = 7     /* a library invariant failed / host allocation failed */
 } egs_status;
 
 /* sparse_iterations.cc:21-26 */
@@ -75,7 +81,17 @@ typedef struct {
   int32_t n_tiles;     /* workgroup-resident tiles */
   int32_t n_global;    /* constraints solved by the cross-workgroup path */
   int32_t reserved;    /* 1 = latency schedule (4 lanes per constraint) in use */
+  int32_t schedule;    /* which kernels ran the last GS / SOR solve, egs_schedule_flags */
+  int32_t tile_constraints; /* constraints per workgroup tile of that schedule */
 } egs_solve_stats;
+
+typedef enum {
+  EGS_SCHED_QUAD = 1,          /* quad_solve_kernel: 4 lanes per constraint */
+  EGS_SCHED_ISO = 2,           /* tile_solve_kernel, isotropic-body variant (no stored M^-1 J^T) */
+  EGS_SCHED_QUAD_PATCHES = 4,  /* oversize islands: body patches on the 4-lane kernel */
+  EGS_SCHED_LANE_PATCHES = 8,  /* oversize islands: body patches on the 1-lane kernel */
+  EGS_SCHED_ALL_GLOBAL = 16    /* oversize islands: the all-global kernel */
+} egs_schedule_flags;
 
 void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */
 
@@ -144,6 +160,37 @@ egs_status egs_problem_get_lambda(egs_problem *p, double *x /*[3m]*/);
 /* a_b = Minv_b sum_i J_ib^T lambda_i, [n][6]: the solver's by-product,
  * so that v_dot = Minv f_ext + a (ensembles.cc:535) needs no extra pass. */
 egs_status egs_problem_get_accumulators(egs_problem *p, double *a /*[n][6]*/);
+
+/* w = A lambda - rhs of the last solve, [3m]: what GetResidualError
+ * (sparse_iterations.cc:51-69) reduces; written by the solve kernels' epilogue. */
+egs_status egs_problem_get_wres(egs_problem *p, double *w /*[3m]*/);
+
+/* ---- the matrix-free products: replace sparse::CalculateSparse{JMJtX,Lx,Ux,
+ *      LxUx,Dx,UxDx,LxDx}(const ConstraintsList&, const MatrixXd& M_inverse,
+ *      const VectorXd& x, double epsilon_diagonal, double scale_diagonal)
+ *      sparse_iterations_utils.h / sparse_iterations_utils.cc:427-695.
+ * With A = J M^-1 J^T (3m x 3m, never formed):
+ *   EGS_MV_FULL   y = (A + eps I) x                          (:624-695; scale unused)
+ *   EGS_MV_LOWER  y = strictLower(A) x  -- the strict lower triangle of a
+ *                 constraint's own 3x3 block belongs to it   (:427-493, :484-486)
+ *   EGS_MV_UPPER  y = strictUpper(A) x                       (:495-561, :522-524)
+ *   EGS_MV_DIAG   y_r = ((A_rr + eps) * scale) x_r           (:571-603, :594)
+ * and the sums the reference offers, added in its order: LOWER|UPPER (:563-569),
+ * UPPER|DIAG (:606-613), LOWER|DIAG (:615-622).  The reference walks all O(m^2)
+ * constraint pairs; here the cost is O(m).
+ * Uses the blocks the problem holds (set_blocks or assemble).  x = NULL takes
+ * the device-resident lambda of the last solve; y = NULL leaves the result on
+ * the device (egs_problem_get_matvec) and makes the call asynchronous.        */
+typedef enum { EGS_MV_LOWER = 1, EGS_MV_UPPER = 2, EGS_MV_DIAG = 4, EGS_MV_FULL = 8 } egs_matvec_part;
+egs_status egs_problem_matvec(egs_problem *p, int32_t parts, double eps, double scale,
+                              const double *x /*[3m] or NULL*/, double *y /*[3m] or NULL*/);
+egs_status egs_problem_get_matvec(egs_problem *p, double *y /*[3m]*/);
+/* one-shot form over flat host arrays, as egs_solve_blocks (the adapter's
+ * sparse::CalculateSparse* functions call this) */
+egs_status egs_matvec_blocks(egs_context *ctx, int32_t n_bodies, const double *Minv, int32_t m,
+                             const int32_t *body0, const int32_t *body1, const double *J0,
+                             const double *J1, int32_t parts, double eps, double scale,
+                             int32_t precision, const double *x, double *y);
 
 /* ---- entry 2: replaces the assembly half of Ensemble::StepVelocities_ODE
  *      (ensembles.cc:563-575): ComputeJ (ensembles.cc:38-87 ->
@@ -279,6 +326,24 @@ egs_status egs_debug_plan_slots(int32_t n_bodies, int32_t m, const int32_t *body
                                 const int32_t *body1, int32_t tile_size,
                                 int32_t *lane, int32_t *slot0, int32_t *slot1,
                                 int32_t *tile_nslots);
+
+/* Which kernel takes islands larger than a workgroup in a GS / SOR solve (host only, the
+ * chooser the library itself uses): 0 = body patches on the 4-lanes-per-constraint kernel,
+ * 1 = body patches on the 1-lane kernel, 2 = the all-global kernel.  Patches wait on each
+ * other, so their count must not exceed (workgroups per CU of the kernel, as
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the exact instantiation) x CUs.  */
+int32_t egs_debug_choose_oversize_schedule(int32_t n_patch_tiles, int32_t quad_per_cu,
+                                           int32_t patch_per_cu, int32_t cu_count,
+                                           int32_t patches_enabled, int32_t quad_patches_enabled);
+
+/* The schedule of the matrix-free products (host only): constraints are
+ * partitioned into workgroup tiles; a body touched from more than one tile is
+ * "shared" and its constraints form the boundary list that a pre-pass publishes.
+ * cons_tile / cons_lane [m], may be NULL.  tile_size = 128 or 256.               */
+egs_status egs_debug_matvec_plan(int32_t n_bodies, int32_t m, const int32_t *body0,
+                                 const int32_t *body1, int32_t tile_size, int32_t *n_tiles,
+                                 int32_t *n_islands, int32_t *n_shared_bodies,
+                                 int32_t *n_boundary, int32_t *cons_tile, int32_t *cons_lane);
 
 #ifdef __cplusplus
 }

@@ -131,6 +131,21 @@ int orc_fast_iterate_f32(int n, int m, const float *Minv, const int32_t *body0,
                          int max_iters, float tol, int check_every, float *x,
                          float *a_out, float *residual_out);
 
+/* w = A x - rhs row by row (sparse_iterations.cc:57) from x and the accumulators a[n][6]
+ * orc_fast_iterate_f64 returned: the expression of the solve kernels' epilogue. */
+void orc_fast_wres_f64(const orc_system *s, const double *rhs, double cfm, const double *x,
+                       const double *a, double *w);
+
+/* O(nnz) twin of the matrix-free products CalculateSparse{Lx,Ux,Dx,LxUx,UxDx,LxDx,JMJtX}
+ * (sparse_iterations_utils.cc:427-695) in the operation order of the HIP mat-vec
+ * kernels.  parts: bit 0 = L, bit 1 = U, bit 2 = D (sums as the reference adds
+ * them); 8 = the full product with eps on the diagonal.                       */
+void orc_fast_matvec_f64(const orc_system *s, const double *x, int parts, double eps,
+                         double scale, double *y);
+void orc_fast_matvec_f32(int n, int m, const float *Minv, const int32_t *body0, const int32_t *body1,
+                         const float *J0, const float *J1, const float *x, int parts, float eps,
+                         float scale, float *y);
+
 /* ---- dense direct LCP (lcp.cc) ------------------------------------------- */
 /* lcp.cc:157-274.  Returns 1 on success. pivots_out may be NULL. */
 int orc_murty(int dim, const double *A, const double *b, const double *lo,

@@ -217,6 +217,14 @@ def fast_iterate(s, rhs, cfm, method, omega=1.5, max_iters=500, tol=1e-9, check_
     return x, a, it, res.value
 
 
+def fast_wres(s, rhs, cfm, x, a):
+    """w = A x - rhs element by element from x and the accumulators fast_iterate returned."""
+    rhs, x, a = _f64(rhs), _f64(x), _f64(a)
+    w = np.zeros(3 * s.m)
+    lib().orc_fast_wres_f64(s.ref, _p(rhs), C.c_double(cfm), _p(x), _p(a), _p(w))
+    return w
+
+
 def fast_iterate_f32(s, rhs, cfm, method, omega=1.5, max_iters=500, tol=0.0, check_every=1):
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     Minv, J0, J1, lo, hi, rhs = f(s.Minv), f(s.J0), f(s.J1), f(s.lo), f(s.hi), f(rhs)
@@ -227,6 +235,26 @@ def fast_iterate_f32(s, rhs, cfm, method, omega=1.5, max_iters=500, tol=0.0, che
                                     C.c_int(max_iters), C.c_float(tol), C.c_int(check_every),
                                     _p(x), _p(a), C.byref(res))
     return x, a, it, res.value
+
+
+MV_LOWER, MV_UPPER, MV_DIAG, MV_FULL = 1, 2, 4, 8
+
+
+def fast_matvec(s, x, parts=MV_FULL, eps=0.0, scale=1.0):
+    """O(nnz) twin of CalculateSparse{Lx,Ux,Dx,...,JMJtX} in the HIP kernels' operation order."""
+    x = _f64(x)
+    y = np.zeros(3 * s.m)
+    lib().orc_fast_matvec_f64(s.ref, _p(x), C.c_int(parts), C.c_double(eps), C.c_double(scale), _p(y))
+    return y
+
+
+def fast_matvec_f32(s, x, parts=MV_FULL, eps=0.0, scale=1.0):
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    Minv, J0, J1, x = f(s.Minv), f(s.J0), f(s.J1), f(x)
+    y = np.zeros(3 * s.m, np.float32)
+    lib().orc_fast_matvec_f32(C.c_int(s.n), C.c_int(s.m), _p(Minv), _p(s.body0), _p(s.body1), _p(J0), _p(J1),
+                              _p(x), C.c_int(parts), C.c_float(eps), C.c_float(scale), _p(y))
+    return y
 
 
 # ---- dense LCP ------------------------------------------------------------

@@ -1,5 +1,6 @@
 """CPU, world_size 2 over gloo: the N>1 plumbing (shard partition + the one
-statistics reduction).  The per-rank work is a stand-in (a counter): the
+statistics reduction).  Each rank picks its BASELINE config 4 shard with the very
+function bench.py uses (bench.c4_shard_seeds) and builds the shard's ensembles; the
 solve itself needs a GPU and is covered by the -m gpu tests."""
 import os
 import socket
@@ -26,14 +27,22 @@ def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from eggshell_amd import scenes
     r, w, _ = egs_dist.init_process_group("gloo")
-    b, e = egs_dist.shard_range(1024, r, w)            # C4: 1024 independent ensembles
-    units = e - b
-    out = egs_dist.reduce_stats(elapsed_s=1.0 + 0.5 * r, units_done=units * 3, contact_iters=units * 256.0 * 50,
+    seeds = bench.c4_shard_seeds(r, w)                 # C4: ensembles 0..1023, seed = global ensemble index
+    units = len(seeds)
+    # the shard's first and last ensemble, built as bench.run_piles builds them
+    nx, ny, nz, sweeps, prec, dt = bench.WORKLOADS["c4"]
+    ends = [scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=sd) for sd in (seeds[0], seeds[-1])]
+    contacts = sum(e["kind"].shape[0] for e in ends) // 2
+    out = egs_dist.reduce_stats(elapsed_s=1.0 + 0.5 * r, units_done=units * 3, contact_iters=units * float(contacts) * sweeps,
                                 max_residual=0.1 * (r + 1), failed=(r == 1 and False))
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, out))
+    q.put((rank, (out, seeds, float(ends[0]["p"][0, 0]))))
 
 
 def test_two_rank_stats_reduction_gloo():
@@ -49,9 +58,11 @@ def test_two_rank_stats_reduction_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(res[0][1] + res[1][1]) == list(range(1024))   # the shards are a partition of ensembles 0..1023
+    assert res[0][2] != res[1][2]                                # different seeds: different ensembles
     for r in range(2):
-        elapsed, units, citers, resid, failed = res[r]
+        elapsed, units, citers, resid, failed = res[r][0]
         assert elapsed == 1.5                       # MAX over ranks
-        assert units == 1024 * 3                    # SUM of per-rank units
+        assert units == 1024 * 3                    # SUM of per-rank units = 1024 ensembles x steps
         assert citers == 1024 * 256.0 * 50
         assert abs(resid - 0.2) < 1e-15 and failed is False

@@ -188,3 +188,19 @@ def test_plan_slots_are_consistent_and_bank_aware(scene, monkeypatch):
     if scene == "pile":
         assert results["0"][0] > 0 and results["0"][1] > 0
         assert results["1"] == (0, 0)
+
+
+def test_oversize_schedule_chooser_follows_the_occupancy():
+    """Patches wait on each other: their count is capped by (resident workgroups per CU, as the
+    occupancy query reports for the kernel) x CUs, and the island falls through to the next
+    schedule when it does not fit (faked occupancies; the library feeds the runtime's)."""
+    ch = capi.debug_choose_oversize_schedule
+    assert ch(157, 1, 2) == 0            # the 64x64 wall: 157 patches, one 1024-thread patch per CU
+    assert ch(256, 1, 2) == 0 and ch(257, 1, 2) == 1 and ch(512, 1, 2) == 1 and ch(513, 1, 2) == 2
+    assert ch(157, 0, 2) == 1            # the 4-lane kernel no longer fits a CU: 1-lane patches
+    assert ch(300, 1, 1) == 2 and ch(256, 0, 1) == 1   # 1-lane kernel at one workgroup per CU
+    assert ch(157, 0, 0) == 2            # nothing resident: the all-global kernel
+    assert ch(157, 4, 8) == 0 and ch(600, 4, 8) == 2   # never above the measured one / two per CU
+    assert ch(100, 1, 2, cu_count=64) == 1 and ch(130, 1, 2, cu_count=64) == 2   # fewer CUs (partitioned device)
+    assert ch(10, 1, 2, patches=False) == 2 and ch(10, 1, 2, quad_patches=False) == 1
+    assert ch(0, 1, 2) == 2
