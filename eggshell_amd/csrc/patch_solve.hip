@@ -2,12 +2,13 @@
 // than a workgroup (connected piles), cut into body patches by plan.cpp.
 //
 // One workgroup per patch tile, one constraint per lane, constraint blocks in
-// VGPRs exactly as in tile_solve_kernel.  A body touched by this patch only
-// keeps its accumulator and ticket in LDS (hand-off ~ an LDS round trip); a
-// body shared with other patches keeps them in global memory and is handed off
-// with sc1 write-through stores -> s_waitcnt vmcnt(0) -> sc1 ticket store;
-// sc1 ticket poll -> sc1 loads (same lane on both ends, guide G16 "sc1 both
-// sides").  Per-body list order is enforced by the same ticket protocol, so the
+// VGPRs exactly as in tile_solve_kernel.  Every body the patch touches has an LDS
+// slot (hand-off ~ an LDS round trip).  A body shared with other patches travels
+// with the sweep: its accumulator and ticket stay in the LDS of the patch that
+// updated it last and cross global memory only where the list-order neighbour on
+// that body sits in another patch (kPrevRemote / kNextRemote, plan.h): sc1
+// write-through stores -> s_waitcnt vmcnt(0) -> sc1 ticket store; sc1 ticket poll
+// -> sc1 loads (same lane on both ends, guide G16 "sc1 both sides").  Per-body list order is enforced by the same ticket protocol, so the
 // result is the sequential list-order sweep, bit for bit.  All patch tiles of a
 // launch must be co-resident (the host caps the grid); every wait is bounded.
 #include "kernels.h"
@@ -36,8 +37,10 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
   const LaneDesc d = A.lanes[(size_t)tile * 256 + tid];
   const bool active = d.cidx >= 0;
   const bool has0 = active && d.slot0 != 0, has1 = active && d.slot1 != 0;
-  const bool sh0 = has0 && d.slot0 == kSharedSlot, sh1 = has1 && d.slot1 == kSharedSlot;
-  const int slot0 = sh0 ? 0 : d.slot0, slot1 = sh1 ? 0 : d.slot1;   // shared sides park on the zero slot
+  const int slot0 = d.slot0 & kSlotMask, slot1 = d.slot1 & kSlotMask;
+  const bool sh0 = has0 && slot_body[slot0] < -1, sh1 = has1 && slot_body[slot1] < -1;   // bodies other patches touch too
+  const bool prev0 = has0 && (d.slot0 & kPrevRemote) != 0, next0 = has0 && (d.slot0 & kNextRemote) != 0;
+  const bool prev1 = has1 && (d.slot1 & kPrevRemote) != 0, next1 = has1 && (d.slot1 & kNextRemote) != 0;
   const int gb0 = active ? A.body0[d.cidx] : -1, gb1 = active ? A.body1[d.cidx] : -1;
   const unsigned cnt0 = d.cnt0, cnt1 = d.cnt1, pos0 = d.pos0, pos1 = d.pos1;
   REAL *ga0 = A.acc + (size_t)(gb0 >= 0 ? gb0 : 0) * 6, *ga1 = A.acc + (size_t)(gb1 >= 0 ? gb1 : 0) * 6;
@@ -66,21 +69,31 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
   while (alive) {
     unsigned t0, t1;
     REAL a0[6], a1[6];
+    // The accumulator comes from global memory when the predecessor on the body (in the order of
+    // this phase: phase 0 and the forward sweep run the list, the backward sweep runs it from its
+    // end) sits in another patch, and goes there when the successor does.  A shared body's first
+    // update of a resumed launch reads global memory, its last update of the launch writes it.
+    const bool fwd = METHOD == 1 || phase == 0;
+    const unsigned o0 = phase == 0 ? pos0 : ord0, o1 = phase == 0 ? pos1 : ord1;
+    const bool acq0 = (fwd ? prev0 : next0) || (sh0 && A.resume && phase == 1 && o0 == 0u);
+    const bool acq1 = (fwd ? prev1 : next1) || (sh1 && A.resume && phase == 1 && o1 == 0u);
+    const bool rel0 = (fwd ? next0 : prev0) || (sh0 && phase == A.sweeps && o0 == cnt0 - 1u);
+    const bool rel1 = (fwd ? next1 : prev1) || (sh1 && phase == A.sweeps && o1 == cnt1 - 1u);
     unsigned g0 = want0, g1 = want1;
-    if (sh0) g0 = gld(gt0);
-    if (sh1) g1 = gld(gt1);
+    if (acq0) g0 = gld(gt0);
+    if (acq1) g1 = gld(gt1);
     poll_ticks(tk0, tk1, t0, t1);   // tickets first, accumulators only when it is this lane's turn (see kernels.hip)
-    if (sh0) t0 = g0;
-    if (sh1) t1 = g1;
+    if (acq0) t0 = g0;
+    if (acq1) t1 = g1;
     const bool ready = (!has0 || t0 == want0) && (!has1 || t1 == want1);
     if (ready) {
       load12(ac0, ac1, a0, a1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (sh0) {
+      if (acq0) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) a0[q] = gld(ga0 + q);
       }
-      if (sh1) {
+      if (acq1) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) a1[q] = gld(ga1 + q);
       }
@@ -95,7 +108,7 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
       }
       if (has0) {
         acc_add(a0, c.B0, dx);
-        if (sh0) {
+        if (rel0) {
 #pragma unroll
           for (int q = 0; q < 6; ++q) gst(ga0 + q, a0[q]);
         } else {
@@ -104,7 +117,7 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
       }
       if (has1) {
         acc_add(a1, c.B1, dx);
-        if (sh1) {
+        if (rel1) {
 #pragma unroll
           for (int q = 0; q < 6; ++q) gst(ga1 + q, a1[q]);
         } else {
@@ -126,12 +139,12 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
           for (int q = 0; q < 6; ++q) ha[q] = a1[q];
         }
       }
-      if (sh0 || sh1) {
+      if (rel0 || rel1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (has0) { if (sh0) gst(gt0, want0 + 1u); else store_tick(tk0, want0 + 1u); }
-      if (has1) { if (sh1) gst(gt1, want1 + 1u); else store_tick(tk1, want1 + 1u); }
+      if (has0) { if (rel0) gst(gt0, want0 + 1u); else store_tick(tk0, want0 + 1u); }
+      if (has1) { if (rel1) gst(gt1, want1 + 1u); else store_tick(tk1, want1 + 1u); }
       asm volatile("s_wakeup");   // wavefronts of this workgroup that sleep on an LDS ticket
       ++phase;
       want0 = base0 + (unsigned)(phase - 1) * cnt0 + ord0;
@@ -145,7 +158,7 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
     if (!__any(ready)) {
       // a lane that waits on a body shared with another workgroup has to keep looking at global
       // memory; a wavefront whose lanes all wait on LDS tickets is woken by s_wakeup
-      if (__any(alive && (sh0 || sh1))) __builtin_amdgcn_s_sleep(1);
+      if (__any(alive && (acq0 || acq1))) __builtin_amdgcn_s_sleep(1);
       else __builtin_amdgcn_s_sleep(32);
     }
   }
@@ -160,6 +173,7 @@ __global__ void __launch_bounds__(256) patch_solve_kernel(const SolveArgs<REAL> 
   // follow-up kernel, once every patch has finished)
   for (int s = tid + 1; s < nslots; s += 256) {
     const int body = slot_body[s];
+    if (body < 0) continue;   // a shared body: its last update of the launch went to global memory
 #pragma unroll
     for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
   }

@@ -96,30 +96,60 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
   plan.patch_lanes.assign((size_t)np * block, idle);
   plan.patch_tile_nslots.assign(np, 1);
   plan.patch_tile_slot_off.assign(np, 0);
+  // LDS slots: one per (patch, body it touches), private or shared.  A shared body's accumulator
+  // travels with the sweep: it stays in the LDS of the patch that updated it last and goes through
+  // global memory only when the NEXT constraint on the body (list order, cyclically) belongs to
+  // another patch.  The two bits on top of a side's slot number say so: kPrevRemote = the
+  // list-order predecessor on that body sits in another patch, kNextRemote = the successor does.
   std::vector<int32_t> fill(np, 0), slot_of(n_bodies, -1);
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> shared_slot(n_bodies);   // (patch, slot) of a shared body
   std::vector<std::vector<int32_t>> tile_bodies(np);
+  std::vector<uint16_t> side_flags((size_t)mg * 2, 0);
+  for (int b = 0; b < n_bodies; ++b) {
+    if (!shared[b]) continue;
+    const int k_n = (int)touch[b].size();
+    for (int k = 0; k < k_n; ++k) {
+      auto tile_of = [&](int kk) { return renum[patch_of[owner(plan.global[touch[b][kk]].cidx)]]; };
+      const int t = tile_of(k), tp = tile_of((k + k_n - 1) % k_n), tn = tile_of((k + 1) % k_n);
+      const int g = touch[b][k], c = plan.global[g].cidx;
+      const int side = (body0[c] == b) ? 0 : 1;
+      side_flags[(size_t)g * 2 + side] = (uint16_t)((tp != t ? kPrevRemote : 0) | (tn != t ? kNextRemote : 0));
+    }
+  }
+  bool overflow = false;
   for (int g = 0; g < mg; ++g) {              // list order -> lanes ascending by list index
     const int c = plan.global[g].cidx;
     const int t = renum[patch_of[owner(c)]];
-    auto slot = [&](int b) -> uint16_t {
+    auto slot = [&](int b, int side) -> uint16_t {
       if (b < 0) return 0;
-      if (shared[b]) return kSharedSlot;
-      if (slot_of[b] < 0) { slot_of[b] = plan.patch_tile_nslots[t]++; tile_bodies[t].push_back(b); }
-      return (uint16_t)slot_of[b];
+      int sl = -1;
+      if (shared[b]) {
+        for (auto &ps : shared_slot[b]) if (ps.first == t) sl = ps.second;
+        if (sl < 0) { sl = plan.patch_tile_nslots[t]++; shared_slot[b].emplace_back(t, sl); tile_bodies[t].push_back(-(b + 2)); }
+      } else {
+        if (slot_of[b] < 0) { slot_of[b] = plan.patch_tile_nslots[t]++; tile_bodies[t].push_back(b); }
+        sl = slot_of[b];
+      }
+      if (sl >= (int)kSlotMask) overflow = true;
+      return (uint16_t)(sl | side_flags[(size_t)g * 2 + side]);
     };
     LaneDesc d;
     d.cidx = c;
-    d.slot0 = slot(body0[c]);
-    d.slot1 = slot(body1[c]);
+    d.slot0 = slot(body0[c], 0);
+    d.slot1 = slot(body1[c], 1);
     d.pos0 = (uint16_t)pos0[c]; d.cnt0 = (uint16_t)(body0[c] >= 0 ? cnt[body0[c]] : 0);
     d.pos1 = (uint16_t)pos1[c]; d.cnt1 = (uint16_t)(body1[c] >= 0 ? cnt[body1[c]] : 0);
     plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
+  }
+  if (overflow) {   // cannot happen with <= 512 sides per patch; keep the all-global path if it ever does
+    plan.n_patch_tiles = 0; plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear();
+    return;
   }
   int off = 0;
   for (int t = 0; t < np; ++t) {
     plan.patch_tile_slot_off[t] = off;
     plan.patch_slot_body.push_back(-1);
-    for (int b : tile_bodies[t]) plan.patch_slot_body.push_back(b);
+    for (int b : tile_bodies[t]) plan.patch_slot_body.push_back(b);   // shared bodies as -(body + 2)
     off += plan.patch_tile_nslots[t];
     plan.patch_max_slots = std::max(plan.patch_max_slots, plan.patch_tile_nslots[t]);
   }

@@ -43,17 +43,23 @@ struct Plan {
   std::vector<int32_t> slot_body;     // slot -> global body index (-1 for slot 0)
   std::vector<GlobalDesc> global;     // constraints of oversize islands, list order
   // Oversize islands cut into workgroup-sized PATCHES of bodies (BFS-grown):
-  // a patch tile owns the constraints whose first body lies in the patch.  A
-  // body touched by one patch only keeps its accumulator/ticket in that
-  // workgroup's LDS (slot >= 1); a body touched by several patches is SHARED:
-  // slot == kSharedSlot, accumulator/ticket in global memory.
+  // a patch tile owns the constraints whose first body lies in the patch.  Every
+  // body a patch touches has an LDS slot there (low 14 bits of LaneDesc::slot0/1).
+  // A body touched by one patch only lives in that workgroup's LDS for good.  A
+  // body touched by several patches is SHARED: its accumulator and ticket stay in
+  // the LDS of the patch that updated it last and cross global memory only when the
+  // list-order neighbour on that body belongs to another patch -- kPrevRemote /
+  // kNextRemote on the side's slot say which hand-offs those are.  In
+  // patch_slot_body a shared body is stored as -(body + 2).
   int n_patch_tiles = 0, patch_max_slots = 1;
   std::vector<LaneDesc> patch_lanes;        // n_patch_tiles * block
   std::vector<int32_t> patch_tile_nslots, patch_tile_slot_off, patch_slot_body;
   int n_shared_bodies = 0;
 };
 
-constexpr uint16_t kSharedSlot = 0xFFFF;
+constexpr uint16_t kSlotMask = 0x3FFF;     // LDS slot number of a patch lane's side
+constexpr uint16_t kNextRemote = 0x4000;   // the list-order successor on this body sits in another patch
+constexpr uint16_t kPrevRemote = 0x8000;   // the list-order predecessor does
 
 // Throws std::invalid_argument on out-of-range body indices.
 // block = kAutoQuadBlock: the smallest of 64 / 128 / 256 that holds the largest island

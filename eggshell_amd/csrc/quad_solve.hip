@@ -96,12 +96,16 @@ __device__ __forceinline__ void store3(unsigned acc_addr, const float (&a)[3]) {
 
 // QT = constraints per tile; the workgroup has 4 * QT threads (64 -> 256, 256 -> 1024).
 // PATCH = true: the tile is a body patch of an island larger than a workgroup
-// (plan.cpp::build_patches).  A side whose slot is kSharedSlot belongs to a body
-// that other workgroups touch too: its accumulator and ticket live in global
-// memory (A.acc, g_tick) and are handed over with sc1 stores -> s_waitcnt
-// vmcnt(0) -> sc1 ticket store / sc1 ticket poll -> sc1 loads, as in
-// patch_solve_kernel.  w = A x - rhs is then left to a follow-up kernel (the
-// shared accumulators are final only when every patch has finished).
+// (plan.cpp::build_patches).  A body that other workgroups touch too has an LDS slot
+// here like a private one, and its accumulator travels with the sweep: it stays in
+// the LDS of the patch that updated it last and crosses global memory (A.acc,
+// g_tick) only where the list-order neighbour on that body sits in another patch
+// (kPrevRemote / kNextRemote on the slot): sc1 stores -> s_waitcnt vmcnt(0) -> sc1
+// ticket store / sc1 ticket poll -> sc1 loads, as in patch_solve_kernel.  The last
+// update of the launch on such a body always goes to global memory, and the first
+// one of a resumed launch always comes from there.  w = A x - rhs is left to a
+// follow-up kernel (the shared accumulators are final only when every patch has
+// finished).
 // HIST = true: records the per-sweep snapshots of SolveArgs::hist_x / hist_acc (tolerance-
 // terminated solves); a separate instantiation, so the plain kernel keeps its 96 VGPRs.
 template <typename REAL, int METHOD, int QT, bool PATCH, bool HIST>
@@ -125,14 +129,16 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   const bool active = d.cidx >= 0;
   const int raw_slot = side ? d.slot1 : d.slot0;
   const bool has = active && raw_slot != 0;        // this lane's body is a real body
-  const bool sh = PATCH && has && raw_slot == kSharedSlot;   // ... shared with other workgroups
-  const int slot = sh ? 0 : raw_slot;              // shared sides park on the zero slot
+  const int slot = PATCH ? (raw_slot & kSlotMask) : raw_slot;
+  // ... shared with other workgroups: where its list-order neighbours on the body live
+  const bool prev_remote = PATCH && has && (raw_slot & kPrevRemote) != 0, next_remote = PATCH && has && (raw_slot & kNextRemote) != 0;
+  const bool sh = PATCH && has && slot_body[slot] < -1;
   const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
   REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
   unsigned *my_tick = s_tick + slot;
   REAL *g_acc = A.acc;
   uint32_t *g_t = g_tick;
-  if (sh) {
+  if (sh) {   // where the accumulator crosses between patches
     const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
     g_acc = A.acc + (size_t)body * 6 + 3 * half;
     g_t = g_tick + body;
@@ -178,34 +184,39 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     // accumulators from x0 = rhs (sparse_iterations.cc:202), list order per body
     bool pending = has;
     unsigned spins = 0;
+    // list order: the value comes from global memory if the predecessor on the body is remote
+    // (pos 0: both places hold zeros) and goes there if the successor is
+    // (a launch without sweeps ends here: then the body's last update goes to global memory)
+    const bool acq = prev_remote, rel = next_remote || (sh && A.sweeps == 0 && pos == cnt - 1u);
     while (pending) {
-      if (sh) {
-        if (gld(g_t) == pos) {
+      const unsigned t = acq ? gld(g_t) : lds_load_acquire(my_tick);
+      if (t == pos) {
+        REAL a[3];
+        if (acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            REAL t = tfma(Bh[3 * k + 0], x[0], gld(g_acc + k));
-            t = tfma(Bh[3 * k + 1], x[1], t);
-            t = tfma(Bh[3 * k + 2], x[2], t);
-            gst(g_acc + k, t);
-          }
+          for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a[k] = my_acc[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          REAL u = tfma(Bh[3 * k + 0], x[0], a[k]);
+          u = tfma(Bh[3 * k + 1], x[1], u);
+          a[k] = tfma(Bh[3 * k + 2], x[2], u);
+        }
+        if (rel) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gst(g_acc + k, a[k]);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both halves' stores (one wavefront) have landed
           if (half == 0) gst(g_t, pos + 1u);
-          pending = false;
-        } else if (++spins > A.spin_limit) {
-          ok = false;
-          pending = false;
-        }
-      } else if (lds_load_acquire(my_tick) == pos) {
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          REAL t = tfma(Bh[3 * k + 0], x[0], my_acc[k]);
-          t = tfma(Bh[3 * k + 1], x[1], t);
-          t = tfma(Bh[3 * k + 2], x[2], t);
-          my_acc[k] = t;
+          for (int k = 0; k < 3; ++k) my_acc[k] = a[k];
+          if (half == 0) lds_store_release(my_tick, pos + 1u);
         }
-        if (half == 0) lds_store_release(my_tick, pos + 1u);
         pending = false;
       } else if (++spins > A.spin_limit) {
         ok = false;
@@ -222,18 +233,24 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     unsigned spins = 0;
     bool alive = active && A.sweeps >= 1;
     const unsigned tick_addr = lds_addr(my_tick), acc_addr = lds_addr(my_acc);
+    // sweep order: forward = list order, backward = reversed, so the neighbours swap roles
+    const bool acq_side = (METHOD == 1) ? prev_remote : next_remote, rel_side = (METHOD == 1) ? next_remote : prev_remote;
     while (alive) {
       unsigned t;
       REAL a[3];
+      // a shared body's first update of a resumed launch reads global memory, its last update of
+      // the launch writes it (the accumulator must not stay behind in some patch's LDS)
+      const bool acq = acq_side || (sh && A.resume && sweep == 1 && ord == 0u);
+      const bool rel = rel_side || (sh && sweep == A.sweeps && ord == cnt - 1u);
       unsigned gt = want;
-      if (sh) gt = gld(g_t);
+      if (acq) gt = gld(g_t);
       poll3(tick_addr, acc_addr, t, a);
-      if (sh) t = gt;
+      if (acq) t = gt;
       int rdy = (!has || t == want) ? 1 : 0;
       rdy &= dpp_i<kXor1>(rdy);
       rdy &= dpp_i<kXor2>(rdy);
       if (rdy) {
-        if (sh) {
+        if (acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
@@ -280,7 +297,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             an[k] = tfma(Bh[3 * k + 2], dx[2], u);
             an_hist[k] = an[k];
           }
-          if (sh) {
+          if (rel) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -305,7 +322,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         // Waiting wavefronts sleep and are woken by the next ticket store of their workgroup
         // (see kernels.hip): -5 % on a single C3 pile, -15 % with four piles per launch; slower
         // on body patches (waits on global tickets cannot be woken), so not there.
-        if (!PATCH) asm volatile("s_wakeup");
+        asm volatile("s_wakeup");
         want += cnt;
         spins = 0;
         alive = ++sweep <= A.sweeps;
@@ -313,7 +330,9 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         ok = false;
         alive = false;
       }
-      if (!PATCH && !__any(rdy)) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
+      // a wavefront with a lane that waits on a global ticket has to keep looking (nothing wakes
+      // it); one whose lanes all wait on LDS tickets sleeps until a ticket store of its workgroup
+      if (!__any(rdy) && !(PATCH && __any(alive && acq))) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -344,6 +363,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   }
   for (int s = tid + 1; s < nslots; s += 4 * QT) {
     const int body = slot_body[s];
+    if (body < 0) continue;   // a shared body: its last update of the launch went to global memory
 #pragma unroll
     for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
   }
