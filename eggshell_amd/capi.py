@@ -34,6 +34,7 @@ EXPORTS = [
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
     "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule",
+    "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
 
@@ -180,13 +181,14 @@ class Context:
                                               C.byref(m), _p(b0), _p(b1), _p(data)))
         return b0[:m.value].copy(), b1[:m.value].copy(), data[:m.value].copy()
 
-    def mixed_constraints_solve(self, A, b, Ceq, lo, hi, use_bounds=0):
+    def mixed_constraints_solve(self, A, b, Ceq, lo, hi, use_bounds=0, max_pivots=0, max_seconds=0.0):
         A, b, lo, hi = map(_f64, (A, b, lo, hi))
         Ceq = _u8(Ceq)
         N = b.shape[0]
         x = np.zeros(N); w = np.zeros(N); ok = C.c_int32(0); piv = C.c_int32(0)
-        st = load().egs_mixed_constraints_solve(self.h, C.c_int32(N), _p(A), _p(b), _p(Ceq), _p(lo), _p(hi),
-                                                C.c_int32(use_bounds), _p(x), _p(w), C.byref(ok), C.byref(piv))
+        st = load().egs_mixed_constraints_solve_limits(self.h, C.c_int32(N), _p(A), _p(b), _p(Ceq), _p(lo), _p(hi),
+                                                       C.c_int32(use_bounds), C.c_int32(max_pivots), C.c_double(max_seconds),
+                                                       _p(x), _p(w), C.byref(ok), C.byref(piv))
         if st not in (OK, ERR_LCP_FAILED):
             self.check(st)
         return bool(ok.value), x, w, piv.value
@@ -291,6 +293,26 @@ class Problem:
         y = np.zeros(3 * self.m)
         self.ctx.check(load().egs_problem_get_matvec(self.h, _p(y)))
         return y
+
+    def dense_system(self, cfm=0.0):
+        """A = J M^-1 J^T + cfm I (ensembles.cc:510, 513-521), built on the device."""
+        A = np.zeros((3 * self.m, 3 * self.m))
+        self.ctx.check(load().egs_problem_dense_system(self.h, C.c_double(cfm), _p(A)))
+        return A
+
+    def dense_condition(self, cfm=0.0):
+        est = C.c_double(0)
+        self.ctx.check(load().egs_problem_dense_condition(self.h, C.c_double(cfm), C.byref(est)))
+        return est.value
+
+    def step_dense(self, dt, erp=0.2, cfm=0.0, use_bounds=0):
+        """StepVelocities_ODE through the dense path: returns (ok, pivots)."""
+        ok = C.c_int32(0); piv = C.c_int32(0)
+        st = load().egs_problem_step_dense(self.h, C.c_double(dt), C.c_double(erp), C.c_double(cfm), C.c_int32(use_bounds),
+                                           C.byref(ok), C.byref(piv))
+        if st not in (OK, ERR_LCP_FAILED):
+            self.ctx.check(st)
+        return bool(ok.value), piv.value
 
     def accumulators(self):
         a = np.zeros((self.n, 6))

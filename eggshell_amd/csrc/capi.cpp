@@ -225,6 +225,9 @@ struct egs_problem {
   DevBuf<uint16_t> mv_ents;
   DevBuf<MvBoundary> mv_boundary;
   DevBuf<unsigned char> mv_T, mv_x, mv_y;
+  DevBuf<unsigned char> tmp_rows;   // [3m] REAL scratch
+  DevBuf<double> dense_A;        // J M^-1 J^T + cfm I of the dense path (egs_problem_dense_system), [3m][3m]
+  double dense_cfm = -1.0;       // the cfm dense_A was built with (< 0: not built)
   bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
   size_t real_size() const { return precision == EGS_F32 ? sizeof(float) : sizeof(double); }
@@ -774,6 +777,37 @@ egs_status do_matvec(egs_problem *p, int32_t parts, double eps, double scale, co
   return EGS_OK;
 }
 
+// The dense system of Ensemble::ComputeVDot (ensembles.cc:510, 513-521) from the blocks the problem holds.
+egs_status build_dense_system(egs_problem *p, double cfm) {
+  egs_context *ctx = p->ctx;
+  if (p->precision != EGS_F64) return fail(ctx, EGS_ERR_UNSUPPORTED, "the dense path is fp64 (the reference's is)");
+  if (!p->have_blocks) return fail(ctx, EGS_ERR_INVALID, "no system uploaded (set_blocks or assemble first)");
+  if ((size_t)p->m * 3 > 46340) return fail(ctx, EGS_ERR_INVALID, "dense system too large (more than 2^31 entries)");
+  const size_t N = (size_t)p->m * 3;
+  p->dense_A.alloc(N * N > 0 ? N * N : 1);
+  launch_dense_system(p->m, p->body0.p, p->body1.p, reinterpret_cast<const double *>(p->J0.p),
+                      reinterpret_cast<const double *>(p->J1.p), p->Minv_d.p, cfm, p->dense_A.p, ctx->stream);
+  HIPCHK(hipGetLastError());
+  p->dense_cfm = cfm;
+  return EGS_OK;
+}
+
+// lambda -> the accumulators a_b = M_b^-1 sum_i J_ib^T lambda_i the velocity update reads: the solve
+// kernels' own list-order accumulation (a launch without sweeps builds them from x0 = rhs, so lambda
+// is lent to it as the rhs).
+void accumulators_from_lambda(egs_problem *p) {
+  egs_solve_params prm;
+  egs_default_params(&prm);
+  prm.method = EGS_GAUSS_SEIDEL; prm.tol = 0.0; prm.max_iters = 0;
+  hipStream_t s = p->ctx->stream;
+  const size_t bytes = (size_t)p->m * 3 * p->real_size();
+  p->tmp_rows.alloc(bytes > 0 ? bytes : 1);
+  HIPCHK(hipMemcpyAsync(p->tmp_rows.p, p->rhs.p, bytes, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(p->rhs.p, p->x.p, bytes, hipMemcpyDeviceToDevice, s));
+  launch_solve(p, prm, 0, 0);     // x = "rhs" (= lambda), acc = sum B x in list order
+  HIPCHK(hipMemcpyAsync(p->rhs.p, p->tmp_rows.p, bytes, hipMemcpyDeviceToDevice, s));
+}
+
 // egs_solve_blocks / egs_matvec_blocks are stateless for their caller; the context keeps the
 // last problem (schedule + device buffers) and reuses it while the constraint graph is unchanged.
 egs_status oneshot_problem(egs_context *ctx, int32_t n, int32_t m, const int32_t *body0, const int32_t *body1,
@@ -960,6 +994,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   p->h_body1.assign(body1, body1 + m);
   p->tile_plan_ready = false;
   p->mv_ready = false;
+  p->dense_cfm = -1.0;
   p->use_quad = false;
   p->have_blocks = false;
   p->have_constraints = false;
@@ -1350,9 +1385,80 @@ egs_status egs_debug_matvec_plan(int32_t n, int32_t m, const int32_t *body0, con
   }
 }
 
+egs_status egs_problem_dense_system(egs_problem *p, double cfm, double *A) {
+  if (!p) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    if (egs_status st = build_dense_system(p, cfm)) return st;
+    const size_t N = (size_t)p->m * 3;
+    if (A && N) {
+      HIPCHK(hipMemcpyAsync(A, p->dense_A.p, N * N * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+      HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    }
+    return EGS_OK;
+  });
+}
+
+egs_status egs_problem_dense_condition(egs_problem *p, double cfm, double *estimate) {
+  if (!p || !estimate) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    if (egs_status st = build_dense_system(p, cfm)) return st;
+    bool spd = true;
+    *estimate = dense_condition_estimate(p->ctx->stream, 3 * p->m, p->dense_A.p, &spd);
+    return EGS_OK;   // not positive definite: +inf, i.e. "ill-conditioned" to the caller (ensembles.cc:514)
+  });
+}
+
+egs_status egs_problem_step_dense(egs_problem *p, double dt, double erp, double cfm, int32_t use_bounds, int32_t *ok,
+                                  int32_t *pivots) {
+  if (!p) return EGS_ERR_INVALID;
+  if (!p->have_state || !p->have_constraints) return fail(p->ctx, EGS_ERR_INVALID, "set_state and set_constraints first");
+  if (!(dt > 0)) return fail(p->ctx, EGS_ERR_INVALID, "dt must be > 0");
+  if (ok) *ok = 0;
+  return guarded(p->ctx, [&]() -> egs_status {
+    egs_context *ctx = p->ctx;
+    hipStream_t s = ctx->stream;
+    if (stall_seen(p)) return report_stall(p);
+    do_assemble(p, dt, erp);                                  // J, err, bounds, rhs (ensembles.cc:565-570)
+    if (p->m == 0) {                                           // v_dot = M^-1 f (ensembles.cc:504-505)
+      HIPCHK(hipMemsetAsync(p->acc.p, 0, (size_t)(p->n > 0 ? p->n : 1) * 6 * p->real_size(), s));
+      do_velocity(p, dt);
+      if (ok) *ok = 1;
+      return EGS_OK;
+    }
+    if (egs_status st = build_dense_system(p, cfm)) return st;   // ensembles.cc:510, 513-521
+    const size_t rows = (size_t)p->m * 3;
+    std::vector<uint8_t> C(rows);
+    std::vector<double> lo(rows), hi(rows);
+    HIPCHK(hipMemcpyAsync(C.data(), p->is_eq.p, rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(lo.data(), p->lo.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hi.data(), p->hi.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int piv = 0;
+    std::string msg;
+    // Lcp::MixedConstraintsSolver (ensembles.cc:531) on the device matrix; lambda lands in the problem's x
+    const bool good = dense_mixed_constraints_device(s, (int)rows, p->dense_A.p, reinterpret_cast<const double *>(p->rhs.p), C.data(),
+                                                     lo.data(), hi.data(), (use_bounds & 1) != 0, (use_bounds & 2) != 0, 0, 0.0,
+                                                     nullptr, nullptr, reinterpret_cast<double *>(p->x.p), &piv, &msg);
+    if (pivots) *pivots = piv;
+    if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "MixedConstraintsSolver did not reach a solution" : msg);
+    if (ok) *ok = 1;
+    p->last_iterations = piv;
+    accumulators_from_lambda(p);                              // a = M^-1 J^T lambda
+    do_velocity(p, dt);                                       // ensembles.cc:535, 572
+    return EGS_OK;
+  });
+}
+
 egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double *A, const double *b,
                                        const uint8_t *C, const double *lo, const double *hi, int32_t use_bounds,
                                        double *x, double *w, int32_t *ok, int32_t *pivots) {
+  return egs_mixed_constraints_solve_limits(ctx, N, A, b, C, lo, hi, use_bounds, 0, 0.0, x, w, ok, pivots);
+}
+
+egs_status egs_mixed_constraints_solve_limits(egs_context *ctx, int32_t N, const double *A, const double *b,
+                                              const uint8_t *C, const double *lo, const double *hi, int32_t use_bounds,
+                                              int32_t max_pivots, double max_seconds, double *x, double *w, int32_t *ok,
+                                              int32_t *pivots) {
   if (!ctx) return EGS_ERR_INVALID;
   if (N < 0 || (N > 0 && (!A || !b || !C || !lo || !hi || !x || !w))) return fail(ctx, EGS_ERR_INVALID, "NULL array");
   if (ok) *ok = 0;
@@ -1361,7 +1467,7 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N, const double
     int piv = 0;
     std::string msg;
     const bool good = dense_mixed_constraints(ctx->stream, N, A, b, C, lo, hi, (use_bounds & 1) != 0,
-                                              (use_bounds & 2) != 0, x, w, &piv, &msg);
+                                              (use_bounds & 2) != 0, x, w, &piv, &msg, max_pivots, max_seconds);
     if (ok) *ok = good ? 1 : 0;
     if (pivots) *pivots = piv;
     if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "MixedConstraintsSolver did not reach a solution" : msg);

@@ -14,8 +14,20 @@ namespace egs {
 // principal pivoting (same solution, far fewer factorisations, no 1000-pivot cap).
 // Returns the reference's bool; *pivots = number of principal pivots (solves).
 // Throws std::invalid_argument / the HIP error type of capi.cpp's hip_check.
+// max_pivots > 0 / max_seconds > 0: give up (return false) after that many principal pivots / that
+// much wall time (lcp::Settings::max_iterations, max_time; toolkit/lcp.h:161-167).
 bool dense_mixed_constraints(hipStream_t stream, int N, const double *A, const double *b, const uint8_t *C,
                              const double *lo, const double *hi, bool use_bounds, bool block_pivoting, double *x,
-                             double *w, int *pivots, std::string *msg);
+                             double *w, int *pivots, std::string *msg, int max_pivots = 0, double max_seconds = 0.0);
+// The same with A (row-major, symmetric: the lower triangle is read) and b already on the device.
+// x / w (host, [N]) may be NULL; dx_out (device, [N]) receives the solution if not NULL.
+bool dense_mixed_constraints_device(hipStream_t stream, int N, const double *dA, const double *db, const uint8_t *C,
+                                    const double *lo, const double *hi, bool use_bounds, bool block_pivoting,
+                                    int max_pivots, double max_seconds, double *x, double *w, double *dx_out,
+                                    int *pivots, std::string *msg);
+// Condition estimate of a symmetric positive definite device matrix from its Cholesky factor:
+// (max_i L_ii / min_i L_ii)^2, a lower bound of the 2-norm condition number the reference gets from
+// a JacobiSVD (utils.cc:256-261).  *spd = false (and +inf) if the factorisation breaks down.
+double dense_condition_estimate(hipStream_t stream, int N, const double *dA, bool *spd);
 
 }  // namespace egs

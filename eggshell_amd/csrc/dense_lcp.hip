@@ -27,6 +27,7 @@
 // failure instead of a wrong answer.
 #include "dense_lcp.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -701,14 +702,17 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, doub
 // tens of factorisations instead of hundreds -- and no min(1000, 2^n) cap, which
 // the reference's single-index rule exhausts for n >~ 600.
 bool murty_device(hipStream_t s, int n, const double *dA, const double *db, const std::vector<double> &lo,
-                  const std::vector<double> &hi, bool box_fix, bool block, double *dx, double *dw, int *pivots_out,
-                  std::string *msg) {
+                  const std::vector<double> &hi, bool box_fix, bool block, int max_pivots, double max_seconds, double *dx,
+                  double *dw, int *pivots_out, std::string *msg) {
+  const auto t_start = std::chrono::steady_clock::now();
   for (int i = 0; i < n; ++i)   // lcp.cc:161-164; the box variant also admits hi == 0 (toolkit/lcp.h:129)
     if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(box_fix ? hi[i] >= 0 : hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
   *pivots_out = 0;
   if (n == 0) return true;
   const double p2 = std::pow(2.0, n);
-  const int max_iterations = block ? 4 * n + 100 : (p2 > 1000 ? 1000 : (int)p2);  // lcp.cc:168
+  int max_iterations = block ? 4 * n + 100 : (p2 > 1000 ? 1000 : (int)p2);  // lcp.cc:168
+  // the caller's own cap (lcp::Settings::max_iterations, toolkit/lcp.h:161-164): give up and return false
+  if (max_pivots > 0 && max_pivots < max_iterations) max_iterations = max_pivots;
   if (n <= kSmallMurtyMax && !block) {   // the whole loop in one workgroup, one read-back
     Buf<double> lo_s(n), hi_s(n);
     Buf<SmallMurtyResult> res_d(1);
@@ -772,7 +776,12 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     check(dx, dw, r.p, &rc);
     best_good = rc.goodness; have_best_good = true;
   }
+  bool timed_out = false;
   while (iter < max_iterations) {
+    if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > max_seconds) {
+      timed_out = true;   // lcp::Settings::max_time (toolkit/lcp.h:166-167)
+      break;
+    }
     if (!force) {
       if (is_solution(rc, 1e-9)) { solved = true; break; }
       if (rc.first_offender == 0x7fffffff) {
@@ -847,7 +856,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     }
     ++iter;
   }
-  if (!solved && iter < max_iterations) solved = is_solution(rc, 1e-9);
+  if (!solved && iter < max_iterations && !timed_out) solved = is_solution(rc, 1e-9);
   *pivots_out = pivots;
   int fail = 0;
   HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -870,7 +879,69 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
 
 bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double *b, const uint8_t *C, const double *lo,
                              const double *hi, bool use_bounds, bool block_pivoting, double *x, double *w, int *pivots,
-                             std::string *msg) {
+                             std::string *msg, int max_pivots, double max_seconds) {
+  if (pivots) *pivots = 0;
+  if (N == 0) return true;
+  Buf<double> dA((size_t)N * N), db(N);
+  HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
+  return dense_mixed_constraints_device(s, N, dA.p, db.p, C, lo, hi, use_bounds, block_pivoting, max_pivots, max_seconds, x, w,
+                                        nullptr, pivots, msg);
+}
+
+__global__ void scatter_kernel(int n, const int *idx, const double *src, double *dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[idx[k]] = src[k];
+}
+
+// max and min of the diagonal of the factor held in T (the first n columns)
+__global__ void __launch_bounds__(256) diag_minmax_kernel(const double *T, int ld, int n, double *out) {
+  __shared__ double smax[256], smin[256];
+  double mx = 0.0, mn = 1e300;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const double d = T[(size_t)k * ld + k];
+    mx = d > mx ? d : mx;
+    mn = d < mn ? d : mn;
+  }
+  smax[threadIdx.x] = mx; smin[threadIdx.x] = mn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      smax[threadIdx.x] = smax[threadIdx.x + o] > smax[threadIdx.x] ? smax[threadIdx.x + o] : smax[threadIdx.x];
+      smin[threadIdx.x] = smin[threadIdx.x + o] < smin[threadIdx.x] ? smin[threadIdx.x + o] : smin[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = smax[0]; out[1] = smin[0]; }
+}
+
+double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *spd) {
+  if (spd) *spd = true;
+  if (N == 0) return 1.0;
+  const int npad = (N + NB - 1) / NB * NB;
+  Buf<double> T((size_t)(npad + 1) * npad), dinv((size_t)npad * NB), zero(N), mm(2);
+  Buf<int> idx_d(N), fail_d(1);
+  std::vector<int> idx(N);
+  for (int i = 0; i < N; ++i) idx[i] = i;
+  HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(zero.p, 0, N * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p);
+  factor(s, T.p, npad, npad + 1, npad, fail_d.p, dinv.p);
+  hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, s, T.p, npad, N, mm.p);
+  double h[2] = {1, 1};
+  int fail = 0;
+  HIPCHK(hipMemcpyAsync(h, mm.p, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof fail, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (fail || !(h[1] > 0)) { if (spd) *spd = false; return std::numeric_limits<double>::infinity(); }
+  const double r = h[0] / h[1];
+  return r * r;
+}
+
+bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, const double *db_in, const uint8_t *C,
+                                    const double *lo, const double *hi, bool use_bounds, bool block_pivoting, int max_pivots,
+                                    double max_seconds, double *x, double *w, double *dx_out, int *pivots, std::string *msg) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
   std::vector<int> E, I;
@@ -878,10 +949,9 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   const int ne = (int)E.size(), ni = (int)I.size();
   const int nepad = (ne + NB - 1) / NB * NB;
   const int ld = nepad + ni, rows = nepad + ni + 1;
-  Buf<double> dA((size_t)N * N), db(N), T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad), dinv((size_t)nepad * NB);
+  Buf<double> T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad), dinv((size_t)nepad * NB);
   Buf<int> dE(ne), dI(ni), fail_d(1);
-  HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
+  struct { const double *p; } dA{dA_in}, db{db_in};
   if (ne) HIPCHK(hipMemcpyAsync(dE.p, E.data(), ne * sizeof(int), hipMemcpyHostToDevice, s));
   if (ni) HIPCHK(hipMemcpyAsync(dI.p, I.data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
@@ -909,7 +979,7 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   std::vector<double> l2(ni), h2(ni);
   for (int k = 0; k < ni; ++k) { l2[k] = use_bounds ? lo[I[k]] : 0.0; h2[k] = use_bounds ? hi[I[k]] : std::numeric_limits<double>::infinity(); }
   int piv = 0;
-  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, xi.p, wi.p, &piv, msg);
+  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, max_pivots, max_seconds, xi.p, wi.p, &piv, msg);
   if (pivots) *pivots = piv;
   if (!ok) return false;
   // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)
@@ -924,10 +994,14 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
     HIPCHK(hipMemcpyAsync(xih.data(), xi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(wih.data(), wi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
   }
+  if (dx_out) {   // the solution stays on the device too (no host round trip for the caller's next kernel)
+    if (ne) hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ne)), dim3(256), 0, s, ne, dE.p, xe.p, dx_out);
+    if (ni) hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ni)), dim3(256), 0, s, ni, dI.p, xi.p, dx_out);
+  }
   HIPCHK(hipStreamSynchronize(s));
-  for (int i = 0; i < N; ++i) w[i] = 0.0;  // lcp.cc:332-333
-  for (int k = 0; k < ne; ++k) x[E[k]] = xeh[k];
-  for (int k = 0; k < ni; ++k) { x[I[k]] = xih[k]; w[I[k]] = wih[k]; }
+  if (w) for (int i = 0; i < N; ++i) w[i] = 0.0;  // lcp.cc:332-333
+  if (x) for (int k = 0; k < ne; ++k) x[E[k]] = xeh[k];
+  for (int k = 0; k < ni; ++k) { if (x) x[I[k]] = xih[k]; if (w) w[I[k]] = wih[k]; }
   return true;
 }
 

@@ -126,6 +126,10 @@ void launch_convert_minv(int count, const double *src, REAL *dst, hipStream_t s)
 template <typename REAL>
 void launch_minv_iso(int n, const REAL *W, int *flag, hipStream_t s);
 
+// A = J M^-1 J^T + cfm I, [3m][3m] row-major fp64 on the device (ensembles.cc:510, 513-521)
+void launch_dense_system(int m, const int32_t *body0, const int32_t *body1, const double *J0, const double *J1,
+                         const double *Minv, double cfm, double *A, hipStream_t s);
+
 void launch_advance(int n, double *pos, double *R, double *v, double *w, const double *v6, double dt,
                     hipStream_t s);
 

@@ -807,7 +807,61 @@ __global__ void __launch_bounds__(256) global_wres_kernel(const GlobalArgs<REAL>
 
 }  // namespace
 
+// --------------------------------------------------------------------------
+// Dense J M^-1 J^T + cfm I (ensembles.cc:510, 513-521) from the block-sparse form: one lane per
+// pair of constraints writes the 3x3 block (zero when the two share no body).  O(m^2) like the
+// reference's dense product, for the sizes its dense solver is meant for (Chain / Cairn).
+__global__ void __launch_bounds__(256) dense_system_kernel(int m, const int32_t *body0, const int32_t *body1,
+                                                           const double *J0, const double *J1, const double *Minv,
+                                                           double cfm, double *A) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)m * m) return;
+  const int i = (int)(idx / m), j = (int)(idx % m);
+  double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int si = 0; si < 2; ++si) {
+    const int bi = si ? body1[i] : body0[i];
+    if (bi < 0) continue;
+    for (int sj = 0; sj < 2; ++sj) {
+      const int bj = sj ? body1[j] : body0[j];
+      if (bj != bi) continue;
+      const double *Ji = (si ? J1 : J0) + (size_t)i * 18, *Jj = (sj ? J1 : J0) + (size_t)j * 18, *W = Minv + (size_t)bi * 36;
+      double t[18];   // W Jj^T, 6x3
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          double v = W[6 * k] * Jj[6 * q];
+#pragma unroll
+          for (int l = 1; l < 6; ++l) v = __builtin_fma(W[6 * k + l], Jj[6 * q + l], v);
+          t[3 * k + q] = v;
+        }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          double v = blk[3 * r + q];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v = __builtin_fma(Ji[6 * r + k], t[3 * k + q], v);
+          blk[3 * r + q] = v;
+        }
+    }
+  }
+  if (i == j) { blk[0] += cfm; blk[4] += cfm; blk[8] += cfm; }
+  const size_t N = (size_t)3 * m;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) A[((size_t)3 * i + r) * N + 3 * j + q] = blk[3 * r + q];
+}
+
 // ---- launchers ------------------------------------------------------------
+void launch_dense_system(int m, const int32_t *body0, const int32_t *body1, const double *J0, const double *J1,
+                         const double *Minv, double cfm, double *A, hipStream_t s) {
+  if (m <= 0) return;
+  const size_t pairs = (size_t)m * m;
+  hipLaunchKernelGGL(dense_system_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, m, body0, body1, J0, J1, Minv, cfm, A);
+}
+
 template <typename REAL>
 void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int block, hipStream_t s) {
   if (n_tiles <= 0) return;

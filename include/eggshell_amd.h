@@ -250,6 +250,34 @@ egs_status egs_mixed_constraints_solve(egs_context *ctx, int32_t N,
                                        double *x, double *w, int32_t *ok,
                                        int32_t *pivots);
 
+/* The same with the give-up limits of lcp::Settings (toolkit/lcp.h:161-167): max_pivots > 0
+ * / max_seconds > 0 stop the pivoting loop there and the call reports *ok = 0
+ * (EGS_ERR_LCP_FAILED), as SolveLCP returns false.  0 = the library's own cap.   */
+egs_status egs_mixed_constraints_solve_limits(egs_context *ctx, int32_t N, const double *A, const double *b,
+                                              const uint8_t *C, const double *lo, const double *hi,
+                                              int32_t use_bounds, int32_t max_pivots, double max_seconds,
+                                              double *x, double *w, int32_t *ok, int32_t *pivots);
+
+/* ---- the dense front half of Ensemble::ComputeVDot (ensembles.cc:498-538) on
+ *      the device, for the sizes the reference's dense solver is meant for
+ *      (Chain, Cairn): the problem's blocks (assemble or set_blocks) -> dense
+ *      A = J M^-1 J^T + cfm I (ensembles.cc:510, 513-521), [3m][3m] row-major,
+ *      kept on the device; A (host) may be NULL.  fp64 problems only.          */
+egs_status egs_problem_dense_system(egs_problem *p, double cfm, double *A /*[3m][3m] or NULL*/);
+/* What stands in for CheckMatrixCondition (ensembles.cc:514 -> utils.cc:256-287):
+ * the reference takes the 2-norm condition number from a JacobiSVD (Eigen, absent
+ * here); this returns (max L_ii / min L_ii)^2 of the Cholesky factor of A, a lower
+ * bound of it -- +inf when A is not positive definite.  The caller compares with
+ * kGoodConditionNumber = 1e7 (constants.h:12) and picks the cfm of the step.     */
+egs_status egs_problem_dense_condition(egs_problem *p, double cfm, double *estimate);
+/* One StepVelocities_ODE through the reference's LIVE dense path (ensembles.cc:563-575,
+ * 498-538): assemble, dense system with the cfm the caller decided, then
+ * Lcp::MixedConstraintsSolver on the device matrix (use_bounds as in entry 3), v update.
+ * Nothing but 3m row types / bounds crosses PCIe; lambda, accumulators and v_new are
+ * read with egs_problem_get_lambda / get_accumulators / get_velocity.             */
+egs_status egs_problem_step_dense(egs_problem *p, double dt, double erp, double cfm,
+                                  int32_t use_bounds, int32_t *ok, int32_t *pivots);
+
 /* ---- contact generation ("next" row 1): replaces Ensemble::UpdateContacts
  *      (ensembles.cc:445-480 -> CollideBoxAndGround collision.cc:408-436,
  *      CollideBoxes collision.cc:166-388) and the contact-vs-contact pruning of

@@ -1,0 +1,114 @@
+"""GPU (-m gpu): the dense front half of Ensemble::ComputeVDot on the device:
+dense J M^-1 J^T (+ cfm I) from the block-sparse system (ensembles.cc:510, 513-521), the
+condition estimate that stands in for CheckMatrixCondition (ensembles.cc:514), and one
+StepVelocities_ODE through Lcp::MixedConstraintsSolver without the matrix leaving the GPU
+(egs_problem_step_dense) -- the reference's LIVE path for Chain-size ensembles."""
+import numpy as np
+import pytest
+
+from eggshell_amd import capi, scenes
+from helpers import dense_numpy, ode_step, system_from_scene
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def resident(ctx, sc):
+    Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+    f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+    pr = capi.Problem(ctx, sc["p"].shape[0], sc["body0"], sc["body1"])
+    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
+    pr.set_constraints(sc["kind"], sc["data"])
+    return pr
+
+
+@pytest.mark.parametrize("scene", ["chain8", "stack", "mixed"])
+def test_dense_system_matches_the_dense_product(ctx, scene):
+    sc = {"chain8": lambda: scenes.chain(8), "stack": lambda: scenes.box_stack(2, 2, 3, jitter=1e-3, seed=2),
+          "mixed": lambda: scenes.concat([scenes.chain(3), scenes.box_stack(1, 2, 2)])}[scene]()
+    pr = resident(ctx, sc)
+    pr.assemble(1e-3)
+    s, _ = system_from_scene(sc)
+    for cfm in (0.0, 0.01):
+        A = pr.dense_system(cfm)
+        assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max()
+        assert np.abs(A - orc.dense_JMJt(s, cfm)).max() <= 1e-12 * np.abs(A).max()      # oracle's block code
+        assert np.abs(A - dense_numpy(s, cfm)[0]).max() <= 1e-9                          # plain numpy matmul (ensembles.cc:510)
+    pr.close()
+
+
+def test_condition_estimate_is_a_lower_bound_and_flags_singular_systems(ctx):
+    pr = resident(ctx, scenes.chain(8))
+    pr.assemble(1e-3)
+    A = pr.dense_system(0.0)
+    est, cond = pr.dense_condition(0.0), np.linalg.cond(A)
+    assert 1.0 <= est <= cond * (1 + 1e-9) and est < 1e7 and cond < 1e7      # Chain(8): well conditioned either way
+    pr.close()
+    # four contacts under one box make J M^-1 J^T singular: ensembles.cc:514 must add cfm
+    pr = resident(ctx, scenes.box_stack(1, 1, 2))
+    pr.assemble(5e-3)
+    assert not pr.dense_condition(0.0) < 1e7
+    assert pr.dense_condition(0.01) < 1e7
+    pr.close()
+
+
+def test_chain8_trajectory_through_the_dense_path(ctx):
+    """20 x Ensemble::Step(1e-3) of Chain(8) on the device through the dense solver equal the oracle's
+    dense pipeline (helpers.ode_step: dense J M^-1 J^T, condition check, MixedConstraintsSolver,
+    midpoint positions) to 1e-9 -- the reference's live path, SURVEY 3a."""
+    sc = scenes.chain(8)
+    ref = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in sc.items()}
+    pr = resident(ctx, sc)
+    for step in range(20):
+        pr.assemble(1e-3)
+        cfm = 0.0 if pr.dense_condition(0.0) < 1e7 else 0.01          # ensembles.cc:513-521, kGoodConditionNumber
+        ok, piv = pr.step_dense(1e-3, 0.2, cfm)
+        assert ok
+        lam = pr.lambda_()
+        pr.advance(1e-3)
+        lam_ref = ode_step(ref, 1e-3)
+        assert np.abs(lam - lam_ref).max() <= 1e-9 * max(1.0, np.abs(lam_ref).max())
+        pos, R, v, w = pr.state()
+        assert np.abs(pos - ref["p"]).max() <= 1e-9 and np.abs(R - ref["R"]).max() <= 1e-9
+        assert np.abs(v - ref["v"]).max() <= 1e-9 and np.abs(w - ref["w"]).max() <= 1e-9
+    pr.close()
+
+
+def test_dense_step_with_contacts_reproduces_q3_and_the_box_variant(ctx):
+    """Contacts: the reference's dense path ignores the friction box (quirk Q3, lcp.cc:298);
+    use_bounds = 1 solves the true box problem.  Both against the oracle's MixedConstraintsSolver."""
+    sc = scenes.box_stack(2, 1, 2, jitter=1e-3, seed=4)
+    s, err = system_from_scene(sc)
+    f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+    rhs = orc.ode_rhs(sc["v"], sc["w"], s.Minv, f_ext, s.body0, s.body1, s.J0, s.J1, err, 5e-3, 0.2)
+    A = orc.dense_JMJt(s, 0.01)
+    solved = 0
+    for ub in (0, 1):
+        pr = resident(ctx, sc)
+        ok, piv = pr.step_dense(5e-3, 0.2, 0.01, use_bounds=ub)
+        oko, xo, wo, pivo = orc.mixed_constraints(A, rhs, s.is_eq, s.lo, s.hi, ub)
+        assert ok == oko     # the reference's rule may hit its own cap (lcp.cc:168): then both say so
+        if not ok:
+            pr.close()
+            continue
+        solved += 1
+        lam = pr.lambda_()
+        assert np.abs(lam - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max())
+        v6 = orc.velocity_update(sc["v"], sc["w"], s.Minv, f_ext, s.body0, s.body1, s.J0, s.J1, lam, 5e-3)
+        assert np.abs(pr.velocity() - v6).max() <= 1e-9 * max(1.0, np.abs(v6).max())
+        pr.close()
+    assert solved >= 1
+
+
+def test_pivot_and_time_limits_give_up(ctx):
+    """lcp::Settings::max_iterations / max_time (toolkit/lcp.h:161-167): give up and report failure."""
+    rng = np.random.default_rng(1)
+    N = 300
+    M = rng.uniform(-1, 1, (N, N)); A = M.T @ M + 1e-3 * np.eye(N)
+    b = rng.uniform(-1, 1, N); C = np.zeros(N, np.uint8)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, C, np.zeros(N), np.full(N, np.inf), use_bounds=0)
+    assert ok and piv > 20
+    ok2, _, _, piv2 = ctx.mixed_constraints_solve(A, b, C, np.zeros(N), np.full(N, np.inf), use_bounds=0, max_pivots=5)
+    assert not ok2 and piv2 <= 5
+    ok3, _, _, piv3 = ctx.mixed_constraints_solve(A, b, C, np.zeros(N), np.full(N, np.inf), use_bounds=0, max_seconds=1e-6)
+    assert not ok3 and piv3 < piv
