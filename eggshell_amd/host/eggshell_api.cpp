@@ -3,9 +3,14 @@
 // the library cannot reach a GPU the calls throw egs::Error.
 #include "eggshell_api.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
+#include <utility>
 
 namespace egs {
 egs_context *DefaultContext() {
@@ -104,6 +109,12 @@ bool BallAndSocketJoint::Describe(int32_t *kind, double data[7]) const {
   return true;
 }
 
+Vector3d BallAndSocketJoint::GetConstraintPosition() const {  // joints.cc:57-75
+  const Vector3d p0 = b0_->p() + b0_->R() * c0_;
+  if (b1_ == nullptr) return p0;
+  return (p0 + (b1_->p() + b1_->R() * c1_)) / 2;
+}
+
 // ---- contact.cc ----------------------------------------------------------
 VectorXd Contact::ComputeError() const {  // contact.cc:14-22
   VectorXd e(3);
@@ -195,6 +206,42 @@ VectorXd sparse::SORIteration(const ConstraintsList &c, const MatrixXd &M, const
 }
 sparse::LastSolve sparse::GetLastSolve() { return g_last; }
 
+// ---- sparse_iterations_utils.cc:427-695 ------------------------------------------
+namespace {
+VectorXd Product(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x, int32_t parts,
+                 double eps, double scale) {
+  if (constraints.empty()) return VectorXd(0);
+  Flat f = Flatten(constraints, M_inverse);
+  if (x.size() != 3 * f.m) throw egs::Error(EGS_ERR_INVALID, "x size != 3 * constraints");
+  VectorXd y(3 * f.m);
+  egs::check(egs_matvec_blocks(egs::DefaultContext(), f.n, f.Minv.data(), f.m, f.body0.data(), f.body1.data(), f.J0.data(),
+                               f.J1.data(), parts, eps, scale, EGS_F64, x.data(), y.data()));
+  return y;
+}
+}  // namespace
+
+VectorXd sparse::CalculateSparseDx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double epsilon, double scale) {
+  return Product(c, M, x, EGS_MV_DIAG, epsilon, scale);
+}
+VectorXd sparse::CalculateSparseLx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double, double) {
+  return Product(c, M, x, EGS_MV_LOWER, 0.0, 1.0);   // epsilon / scale unused (sparse_iterations_utils.h:69-71)
+}
+VectorXd sparse::CalculateSparseUx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double, double) {
+  return Product(c, M, x, EGS_MV_UPPER, 0.0, 1.0);
+}
+VectorXd sparse::CalculateSparseLxUx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double, double) {
+  return Product(c, M, x, EGS_MV_LOWER | EGS_MV_UPPER, 0.0, 1.0);
+}
+VectorXd sparse::CalculateSparseLxDx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double eps, double scale) {
+  return Product(c, M, x, EGS_MV_LOWER | EGS_MV_DIAG, eps, scale);
+}
+VectorXd sparse::CalculateSparseUxDx(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double eps, double scale) {
+  return Product(c, M, x, EGS_MV_UPPER | EGS_MV_DIAG, eps, scale);
+}
+VectorXd sparse::CalculateSparseJMJtX(const ConstraintsList &c, const MatrixXd &M, const VectorXd &x, double eps) {
+  return Product(c, M, x, EGS_MV_FULL, eps, 1.0);
+}
+
 void sparse::ConstructMixedConstraints(const ConstraintsList &constraints, ArrayXb *C, VectorXd *x_lo,
                                        VectorXd *x_hi) {  // sparse_iterations_utils.cc:697-720
   const int m = (int)constraints.size();
@@ -235,6 +282,7 @@ void Ensemble::Init() {  // ensembles.cc:24-29
   VectorXd err = ComputePositionConstraintError();  // CheckInitialConditions, :224-232
   for (int k = 0; k < err.size(); ++k)
     if (!(std::fabs(err(k)) <= 1e-9)) throw egs::Error(EGS_ERR_INVALID, "Check initial conditions failed.");
+  CheckAndCorrectEnsembleState();                   // ensembles.cc:28
 }
 
 void Ensemble::ConstructMassInertiaMatrixInverse() {  // ensembles.cc:202-212
@@ -336,6 +384,15 @@ VectorXd Ensemble::StepVelocities_ODE(double dt, const VectorXd &v, double erp) 
     egs::check(egs_problem_set_state(problem_, pos.data(), R.data(), vl.data(), w.data(), Minv.data(), external_force_torque_.data()));
     egs::check(egs_problem_set_constraints(problem_, kind.data(), data.data()));
     egs_solve_stats st;
+    if (use_dense_solver) {   // ComputeVDot (ensembles.cc:498-538) on the device
+      egs::check(egs_problem_assemble(problem_, dt, erp));
+      egs::check(egs_problem_dense_condition(problem_, 0.0, &last_condition_estimate));
+      const double cfm = last_condition_estimate < 1e7 ? 0.0 : cfm_coeff;   // kGoodConditionNumber, constants.h:12
+      int32_t ok = 0, pivots = 0;
+      egs_status rc = egs_problem_step_dense(problem_, dt, erp, cfm, /*use_bounds=*/0, &ok, &pivots);
+      if (rc != EGS_OK || !ok)   // the reference Panics here (ensembles.cc:531-534)
+        throw egs::Error(rc != EGS_OK ? rc : EGS_ERR_LCP_FAILED, "Lcp::MixedConstraintsSolver exited without reaching a solution.");
+    } else
     egs::check(egs_problem_step(problem_, dt, erp, &prm, &st));
     last_lambda.resize(3 * m);
     egs::check(egs_problem_get_lambda(problem_, last_lambda.data()));
@@ -410,14 +467,75 @@ void Ensemble::UpdateContacts() {  // ensembles.cc:445-480 (+ :308-328)
   std::vector<int32_t> b0(cap), b1(cap);
   std::vector<double> data((size_t)cap * 7);
   int32_t m = 0;
-  egs::check(egs_update_contacts(egs::DefaultContext(), n_, pos.data(), R.data(), side.data(), cap, &m, b0.data(),
-                                 b1.data(), data.data()));
+  // The reference's Step prunes right after detection (CheckAndCorrectEnsembleState, ensembles.cc:394):
+  // contact-vs-contact always, joint-vs-contact for the joints between the same two components.  Joints
+  // that can describe themselves are pruned against on the device, the others on the host below.
+  std::vector<int32_t> jb0, jb1;
+  std::vector<double> jdata;
+  std::vector<std::shared_ptr<Joint>> host_joints;
+  for (const auto &j : joints_) {
+    if (j->i0_ < 0 || j->i1_ < 0) continue;   // the pair scan never visits the ground (quirk Q4)
+    int32_t kind = 0;
+    double d7[7];
+    if (j->Describe(&kind, d7)) { jb0.push_back(j->i0_); jb1.push_back(j->i1_); jdata.insert(jdata.end(), d7, d7 + 7); }
+    else host_joints.push_back(j);
+  }
+  egs::check(egs_update_contacts_joints(egs::DefaultContext(), n_, pos.data(), R.data(), side.data(), (int32_t)jb0.size(),
+                                        jb0.data(), jb1.data(), jdata.data(), cap, &m, b0.data(), b1.data(), data.data()));
   for (int k = 0; k < m; ++k) {
     const double *d = &data[(size_t)k * 7];
     ContactGeometry cg(Vector3d(d[0], d[1], d[2]), Vector3d(d[3], d[4], d[5]), d[6]);
+    bool keep = true;
+    for (const auto &j : host_joints) {        // ensembles.cc:296-306, kMinConstraintDistance = 1e-6
+      const bool same_pair = (j->i0_ == b0[k] && j->i1_ == b1[k]) || (j->i0_ == b1[k] && j->i1_ == b0[k]);
+      if (same_pair && (j->GetConstraintPosition() - cg.position).norm() < 1e-6) keep = false;
+    }
+    if (!keep) continue;
     if (b0[k] < 0) contacts_.push_back(std::make_shared<Contact>(components_[b1[k]], b1[k], cg));
     else contacts_.push_back(std::make_shared<Contact>(components_[b0[k]], b0[k], components_[b1[k]], b1[k], cg));
   }
+}
+
+// ensembles.cc:241-329.  UpdateContacts already returns a pruned contact list (the device does the
+// contact-vs-contact and joint-vs-contact passes in the reference's order), so what is left for
+// caller-supplied contacts (SetContacts) is the same scan on the host, and the joint-vs-joint check.
+void Ensemble::CheckAndCorrectEnsembleState() {
+  if (M_inverse_.rows() != 6 * n_ || M_inverse_.cols() != 6 * n_) throw egs::Error(EGS_ERR_INVALID, "M_inverse_ dimensions are incorrect.");
+  if (external_force_torque_.size() != 6 * n_) throw egs::Error(EGS_ERR_INVALID, "external_force_torque_ dimensions are incorrect.");
+  auto key_of = [](int a, int b) { return a < b ? std::make_pair(a, b) : std::make_pair(b, a); };
+  auto close = [](const Constraint &c1, const Constraint &c2) {   // CheckConstraintPair, ensembles.cc:376-388
+    return (c1.GetConstraintPosition() - c2.GetConstraintPosition()).norm() < 1e-6;
+  };
+  // joint vs joint: conflict or overconstraint -> the reference Panics (ensembles.cc:280-289)
+  for (size_t a = 0; a < joints_.size(); ++a)
+    for (size_t b = a + 1; b < joints_.size(); ++b) {
+      if (joints_[a]->i0_ < 0 || joints_[a]->i1_ < 0) continue;   // pairs 0 <= i < j only (quirk Q4)
+      if (key_of(joints_[a]->i0_, joints_[a]->i1_) != key_of(joints_[b]->i0_, joints_[b]->i1_)) continue;
+      if (close(*joints_[a], *joints_[b]))
+        throw egs::Error(EGS_ERR_INVALID, "Joint constraints between components " + std::to_string(key_of(joints_[a]->i0_, joints_[a]->i1_).first) +
+                                              " and " + std::to_string(key_of(joints_[a]->i0_, joints_[a]->i1_).second) +
+                                              " conflict or cause overconstraint.");
+    }
+  // joint vs contact, then contact vs contact (the later one goes), pair by pair (the reference's
+  // pairwise maps, ensembles.cc:331-374); erased in descending order
+  std::map<std::pair<int, int>, std::vector<int>> pair_joints, pair_contacts;
+  for (size_t j = 0; j < joints_.size(); ++j)
+    if (joints_[j]->i0_ >= 0 && joints_[j]->i1_ >= 0) pair_joints[key_of(joints_[j]->i0_, joints_[j]->i1_)].push_back((int)j);
+  for (size_t c = 0; c < contacts_.size(); ++c)
+    if (contacts_[c]->i0_ >= 0 && contacts_[c]->i1_ >= 0) pair_contacts[key_of(contacts_[c]->i0_, contacts_[c]->i1_)].push_back((int)c);
+  std::vector<char> drop(contacts_.size(), 0);
+  for (const auto &pc : pair_contacts) {
+    const auto pj = pair_joints.find(pc.first);
+    for (size_t a = 0; a < pc.second.size(); ++a) {
+      const int c = pc.second[a];
+      if (pj != pair_joints.end())
+        for (int j : pj->second) if (close(*joints_[j], *contacts_[c])) drop[c] = 1;
+      for (size_t e = 0; e < a; ++e)   // every earlier contact of the pair takes part, dropped or not (ensembles.cc:308-322)
+        if (close(*contacts_[pc.second[e]], *contacts_[c])) drop[c] = 1;
+    }
+  }
+  for (size_t c = contacts_.size(); c-- > 0;)
+    if (drop[c]) contacts_.erase(contacts_.begin() + (long)c);
 }
 
 // The whole Step through egs_world (include/eggshell_amd.h): possible when every
@@ -425,7 +543,7 @@ void Ensemble::UpdateContacts() {  // ensembles.cc:445-480 (+ :308-328)
 // Body objects are the interface, so their state is pushed before and pulled
 // after the step; inside the step nothing but the contact topology leaves the GPU.
 bool Ensemble::StepOnDevice(double dt) {
-  if (!use_device_step) return false;
+  if (!use_device_step || use_dense_solver) return false;
   const int mj = (int)joints_.size();
   std::vector<int32_t> jb0(mj), jb1(mj), kind(1);
   std::vector<double> jdata((size_t)mj * 7);
@@ -455,9 +573,12 @@ bool Ensemble::StepOnDevice(double dt) {
   // M^-1, the external force and the box sizes are frozen at Init() (Q5): sent once
   egs::check(egs_world_set_bodies(world_, pos.data(), R.data(), vl.data(), w.data(), first ? Minv.data() : nullptr,
                                   first ? external_force_torque_.data() : nullptr, first ? side.data() : nullptr));
-  if (world_joints_ != mj) {   // joints are permanent (ensembles.cc:331-334)
+  // joints are permanent in the reference (ensembles.cc:331-334); a caller that edits them all the same
+  // (same count, other bodies or anchors) must not step against the stale device copy
+  if (world_joints_ != mj || jb0 != world_jb0_ || jb1 != world_jb1_ || jdata != world_jdata_) {
     egs::check(egs_world_set_joints(world_, mj, jb0.data(), jb1.data(), jdata.data()));
     world_joints_ = mj;
+    world_jb0_ = jb0; world_jb1_ = jb1; world_jdata_ = jdata;
   }
   egs_solve_params prm = solver_params;
   prm.cfm = cfm_coeff;
@@ -501,6 +622,7 @@ void Ensemble::Step(double dt, Integrator g) {  // ensembles.cc:390-427
   if (StepOnDevice(dt)) return;   // collide -> solve -> integrate in one resident pipeline
   const VectorXd v = GetVelocities();
   if (detect_contacts) UpdateContacts();
+  CheckAndCorrectEnsembleState();   // ensembles.cc:394
   VectorXd v_new = StepVelocities_ODE(dt, v);
   StepPositions_ODE(dt, v, v_new);
 }
@@ -519,4 +641,29 @@ Chain::Chain(int num_links, const Vector3d &anchor) {  // ensembles.cc:668-707
   for (int i = 0; i < n_ - 1; ++i)
     joints_.push_back(std::make_shared<BallAndSocketJoint>(components_[i], i, c1, components_[i + 1], i + 1, c2));
   joints_.push_back(std::make_shared<BallAndSocketJoint>(components_[0], 0, Vector3d::Zero(), components_[0]->p()));
+}
+
+// ---- Cairn (ensembles.cc:708-728) ------------------------------------------------
+namespace {
+double Rand01() { return double(std::rand()) / double(RAND_MAX); }          // Eigen internal::random<double>(0, 1)
+double RandPm1() { return -1.0 + 2.0 * Rand01(); }                          // ... (-1, 1): Vector3d::Random() per coefficient
+Vector3d RandomVector() { double a = RandPm1(), b = RandPm1(), c = RandPm1(); return Vector3d(a, b, c); }
+}  // namespace
+
+Cairn::Cairn(int num_rocks, const std::array<double, 2> &xb, const std::array<double, 2> &yb, const std::array<double, 2> &zb) {
+  if (num_rocks < 0) throw egs::Error(EGS_ERR_INVALID, "num_rocks >= 0");
+  n_ = num_rocks;
+  const Matrix3d I = Matrix3d::Identity() * 0.1;
+  for (int i = 0; i < num_rocks; ++i) {
+    // RandomPosition, utils.cc:26-38
+    Vector3d u = (RandomVector() + Vector3d(1, 1, 1)) / 2;
+    Vector3d p(u[0] * std::fabs(xb[1] - xb[0]) + std::min(xb[0], xb[1]), u[1] * std::fabs(yb[1] - yb[0]) + std::min(yb[0], yb[1]),
+               u[2] * std::fabs(zb[1] - zb[0]) + std::min(zb[0], zb[1]));
+    // RandomRotationViaQuaternion -> Quaterniond::UnitRandom (utils.cc:52-55)
+    const double u1 = Rand01(), u2 = 2 * M_PI * Rand01(), u3 = 2 * M_PI * Rand01();
+    const double a = std::sqrt(1 - u1), b = std::sqrt(u1);
+    const Matrix3d R = QuatToR(a * std::sin(u2), a * std::cos(u2), b * std::sin(u3), b * std::cos(u3));
+    const Vector3d v = RandomVector() * max_init_v_, w = RandomVector() * max_init_w_;   // utils.cc:40-48
+    components_.push_back(std::make_shared<Body>(p, v, 1.0, R, w, I));
+  }
 }

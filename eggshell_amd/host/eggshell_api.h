@@ -83,6 +83,8 @@ class Constraint {  // constraints.h:14-48
   // for constraint types the library cannot assemble itself (then the solver
   // falls back to flattening ComputeJ on the host, entry 1).
   virtual bool Describe(int32_t *kind, double data[7]) const { (void)kind; (void)data; return false; }
+  // Get the global frame constraint position (constraints.h:38-39).
+  virtual Vector3d GetConstraintPosition() const = 0;
   int i0_ = -1;
   int i1_ = -1;
 
@@ -109,6 +111,7 @@ class BallAndSocketJoint : public Joint {  // joints.h:31-50
   void ComputeJ(MatrixXd *J_b0, MatrixXd *J_b1, ArrayXb *constraint_type, VectorXd *constraint_lo,
                 VectorXd *constraint_hi) const override;                    // joints.cc:13-35
   bool Describe(int32_t *kind, double data[7]) const override;
+  Vector3d GetConstraintPosition() const override;                          // joints.cc:57-75
 };
 
 struct ContactGeometry {  // collision.h:12-27
@@ -127,6 +130,7 @@ class Contact : public Constraint {  // contact.h:11-56
   VectorXd ComputeError() const override;                                   // contact.cc:14-22
   void ComputeJ(MatrixXd *J_b0, MatrixXd *J_b1, ArrayXb *C, VectorXd *x_lo, VectorXd *x_hi) const override;  // :38-117
   bool Describe(int32_t *kind, double data[7]) const override;
+  Vector3d GetConstraintPosition() const override { return cg_.position; }  // contact.cc:166-168
 
  private:
   const ContactGeometry cg_;
@@ -146,6 +150,24 @@ VectorXd SORIteration(const ConstraintsList &constraints, const MatrixXd &M_inve
                       double cfm = 0.0);
 // sparse_iterations_utils.cc:697-720
 void ConstructMixedConstraints(const ConstraintsList &constraints, ArrayXb *C, VectorXd *x_lo, VectorXd *x_hi);
+// The matrix-free products (sparse_iterations_utils.h:60-109, sparse_iterations_utils.cc:427-695):
+// strict lower / strict upper / diagonal parts of (J M^-1 J^T) x and the full product with
+// epsilon on the diagonal.  Same names, arguments and defaults; O(m) on the GPU
+// (egs_matvec_blocks) instead of the reference's O(m^2) pair loops.
+VectorXd CalculateSparseDx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                           double epsilon = 0.0, double scale = 1.0);
+VectorXd CalculateSparseLx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                           double epsilon_diagonal = 0.0, double scale_diagonal = 1.0);
+VectorXd CalculateSparseUx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                           double epsilon_diagonal = 0.0, double scale_diagonal = 1.0);
+VectorXd CalculateSparseLxUx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                             double epsilon_diagonal = 0.0, double scale_diagonal = 1.0);
+VectorXd CalculateSparseLxDx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                             double epsilon_diagonal = 0.0, double scale_diagonal = 1.0);
+VectorXd CalculateSparseUxDx(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                             double epsilon_diagonal = 0.0, double scale_diagonal = 1.0);
+VectorXd CalculateSparseJMJtX(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x,
+                              double epsilon_diagonal = 0.0);
 // Iteration count and residual of the most recent *Iteration call (the
 // reference prints the count to stdout, sparse_iterations.cc:223-224).
 struct LastSolve { int iterations; double residual; int n_islands, n_tiles, n_global; };
@@ -159,12 +181,20 @@ bool MixedConstraintsSolver(const MatrixXd &A, const VectorXd &b, const ArrayXb 
 
 // toolkit/lcp.h:104-174 -- the "adjacent" solver family the north star names
 // (lcp::SolveLCP; not linked into eggshell).  Box LCP
-// A x = b + w with lo <= 0 <= hi; rows with lo = -inf and hi = +inf (or
-// +-DBL_MAX) are unbounded, i.e. equalities, and are eliminated by a Schur
-// complement as SolveLCP_BoxSchur does (toolkit/lcp.cc:627-747).  Differences:
-// `algorithm` selects nothing (block principal pivoting with a single-index
-// safeguard is used for both), A is NOT permuted in place, and
-// max_iterations / max_time are ignored.
+// A x = b + w with lo <= 0 <= hi.  What is kept of the contract:
+//   * the dispatch of toolkit/lcp.cc:752-785, including its two refusals (Schur complement
+//     or Cottle-Dantzig without box_lcp: the reference Panics, here egs::Error / EGS_ERR_INVALID);
+//   * schur_complement: unbounded rows (lo = -inf or -DBL_MAX and hi = +inf or DBL_MAX) are
+//     eliminated first (SolveLCP_BoxSchur, toolkit/lcp.cc:627-747) and A IS PERMUTED IN PLACE
+//     exactly as BoxSchur's two-pointer partition leaves it (unbounded rows first);
+//     quirk Q6 (toolkit/lcp.cc:664, 669 test `hi < -DBL_MAX`, so a row with lo = -inf and a
+//     FINITE hi is classed unbounded) is reproduced when reference_quirks is set;
+//   * max_iterations and max_time: the solve gives up and returns false (toolkit/lcp.h:161-167);
+//   * box_lcp = false: lo = 0, hi = +inf whatever the vectors hold (toolkit/lcp.h:152-154).
+// What differs, by design: `algorithm` picks no different code -- block
+// principal pivoting with a single-index safeguard finds the same unique solution for both
+// -- there is no incremental Cholesky (LinearReducer), so with schur_complement = false A is
+// left untouched instead of carrying the pivoting order of SolveLCP_BoxMurty.
 namespace lcp {
 enum Algorithm { MURTY, COTTLE_DANTZIG };
 struct Settings {
@@ -173,7 +203,9 @@ struct Settings {
   bool schur_complement = true;
   int max_iterations = __INT_MAX__;
   double max_time = __DBL_MAX__;
+  bool reference_quirks = false;   // not in the reference: reproduce Q6 (see above)
 };
+int LastSolvePivots();             // principal pivots of the most recent SolveLCP
 bool SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, const VectorXd &lo, const VectorXd &hi,
               VectorXd *x, VectorXd *w);
 }  // namespace lcp
@@ -201,7 +233,17 @@ class Ensemble {  // ensembles.h:25-186
   // update contacts_ (ensembles.cc:445-480), then drop contacts closer than
   // 1e-6 to an earlier contact of the same pair (ensembles.cc:308-328): on the GPU.
   void UpdateContacts();
+  // Check whether there exist constraint pairs that are too close to each other (ensembles.cc:241-329):
+  // conflicting joints between one pair of components are an error (the reference Panics; here
+  // egs::Error with EGS_ERR_INVALID), a contact closer than 1e-6 to a joint or to an earlier contact
+  // of the same pair is dropped.
+  void CheckAndCorrectEnsembleState();
   bool use_device_step = true;   // false: the explicit UpdateContacts / StepVelocities_ODE / StepPositions_ODE calls
+  // true: StepVelocities_ODE goes through the reference's LIVE dense path on the device (ComputeVDot,
+  // ensembles.cc:498-538: dense J M^-1 J^T, condition check, conditional cfm, Lcp::MixedConstraintsSolver)
+  // instead of the matrix-free sweeps; implies the explicit Step path.
+  bool use_dense_solver = false;
+  double last_condition_estimate = 0;
   bool detect_contacts = true;   // Step() calls UpdateContacts() as the reference does (ensembles.cc:393)
   const VectorXd GetVelocities() const;                                  // ensembles.cc:429-436
   VectorXd ComputePositionConstraintError() const;                       // ensembles.cc:156-171
@@ -237,6 +279,8 @@ class Ensemble {  // ensembles.h:25-186
   void StepPostStabilization(double dt, double step_scale = 0.2);          // ensembles.cc:653-658
   egs_world *world_ = nullptr;
   int world_joints_ = -1;
+  std::vector<int32_t> world_jb0_, world_jb1_;   // the joints the device world holds
+  std::vector<double> world_jdata_;
   egs_problem *problem_ = nullptr;
   std::vector<int32_t> plan_b0_, plan_b1_;   // topology the cached device problem was planned for
 };
@@ -244,6 +288,21 @@ class Ensemble {  // ensembles.h:25-186
 class Chain : public Ensemble {  // ensembles.h:188-198, ensembles.cc:668-707
  public:
   Chain(int num_links, const Vector3d &anchor_position);
+};
+
+// ensembles.h:191-200, ensembles.cc:708-728: num_rocks boxes (m = 1, I = 0.1 I3) suspended at random
+// positions inside the bounds with random rotations, velocities (|v_k| <= 1) and spins.  The
+// reference draws from Eigen's Random (std::rand); so does this, through the same formulas
+// (Vector3d::Random: 2 rand()/RAND_MAX - 1 per coefficient; Quaterniond::UnitRandom), so the
+// scenario family is the reference's -- not its exact numbers, which depend on Eigen's call order.
+class Cairn : public Ensemble {
+ public:
+  Cairn(int num_rocks, const std::array<double, 2> &x_bound, const std::array<double, 2> &y_bound,
+        const std::array<double, 2> &z_bound);
+
+ private:
+  const double max_init_v_ = 1;
+  const double max_init_w_ = 1;
 };
 
 #endif

@@ -5,8 +5,10 @@
 // and all rows equalities.  J J^T is only positive SEMI-definite when contacts
 // are redundant; the correction J^T y is unique whenever err is consistent, and
 // the sweep converges to it.
+#include <algorithm>
 #include <cmath>
 #include <limits>
+#include <vector>
 
 #include "eggshell_api.h"
 
@@ -100,26 +102,74 @@ void Ensemble::PostStabilize(int max_steps) {  // ensembles.cc:624-646
   last_stabilize_steps = step_counter;
 }
 
-// ---- toolkit/lcp.h:172-174 ---------------------------------------------------
+// ---- toolkit/lcp.h:172-174, toolkit/lcp.cc:627-785 ------------------------------
+namespace { int g_last_lcp_pivots = 0; }
+int lcp::LastSolvePivots() { return g_last_lcp_pivots; }
+
 bool lcp::SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, const VectorXd &lo, const VectorXd &hi,
                    VectorXd *x, VectorXd *w) {
   const int N = b.size();
-  if (A.rows() != N || A.cols() != N || !x || !w) throw egs::Error(EGS_ERR_INVALID, "dimension mismatch");
-  if (settings.box_lcp && (lo.size() != N || hi.size() != N)) throw egs::Error(EGS_ERR_INVALID, "lo/hi size");
+  // CHECKs of toolkit/lcp.cc:756-760 (the reference Panics)
+  if (A.rows() != A.cols() || A.rows() <= 0 || A.rows() != N || lo.size() != N || hi.size() != N || !x || !w)
+    throw egs::Error(EGS_ERR_INVALID, "SolveLCP: A must be square and non-empty, b / lo / hi of its size");
+  // the dispatch of toolkit/lcp.cc:762-784 and its refusals
+  if (settings.schur_complement && !settings.box_lcp)
+    throw egs::Error(EGS_ERR_INVALID, "Schur complement solver only available for box LCP");
+  if (!settings.schur_complement && settings.algorithm == COTTLE_DANTZIG && !settings.box_lcp)
+    throw egs::Error(EGS_ERR_INVALID, "Cottle Dantzig solver only available for box LCP");
+  if (settings.algorithm != MURTY && settings.algorithm != COTTLE_DANTZIG) throw egs::Error(EGS_ERR_INVALID, "Unknown LCP solver selection");
   const double inf = std::numeric_limits<double>::infinity();
   VectorXd l(N), h(N);
   ArrayXb C(N);
+  std::vector<char> unbounded(N, 0);
   for (int i = 0; i < N; ++i) {
-    l(i) = settings.box_lcp ? lo(i) : 0.0;
+    l(i) = settings.box_lcp ? lo(i) : 0.0;    // toolkit/lcp.h:152-154
     h(i) = settings.box_lcp ? hi(i) : inf;
-    if (l(i) <= -__DBL_MAX__) l(i) = -inf;   // "infinity" is DBL_MAX or the real infinity (toolkit/lcp.h:149-150)
-    if (h(i) >= __DBL_MAX__) h(i) = inf;
-    C(i) = (l(i) == -inf && h(i) == inf) ? 1 : 0;
+    // "infinity" is DBL_MAX or the real infinity (toolkit/lcp.h:149-150).  A row is unbounded when both
+    // bounds are infinite; the reference tests `hi < -DBL_MAX` (quirk Q6, toolkit/lcp.cc:664, 669), i.e.
+    // the lower bound alone decides.
+    const bool lo_inf = l(i) <= -__DBL_MAX__, hi_inf = h(i) >= __DBL_MAX__;
+    unbounded[i] = settings.schur_complement && (settings.reference_quirks ? lo_inf : (lo_inf && hi_inf));
+    if (lo_inf) l(i) = -inf;
+    if (hi_inf || (unbounded[i] && settings.reference_quirks)) h(i) = inf;   // Q6: the finite hi of such a row is never looked at
+    C(i) = unbounded[i] ? 1 : 0;
+  }
+  if (settings.schur_complement) {
+    // SolveLCP_BoxSchur permutes the problem so that the unbounded rows come first, and A stays permuted
+    // (toolkit/lcp.h:170-171, toolkit/lcp.cc:656-683): the same two-pointer partition, applied to A's rows
+    // and columns.  The solve below works on the unpermuted copy; x and w come back in the caller's order,
+    // as BoxSchur's Unpermute leaves them.
+    std::vector<char> ub = unbounded;
+    const MatrixXd A0 = A;
+    std::vector<int> perm(N);
+    for (int i = 0; i < N; ++i) perm[i] = i;
+    int nub = 0, nb = N - 1;
+    while (true) {
+      for (; nub <= nb; ++nub) if (!ub[nub]) break;
+      for (; nb >= nub; --nb) if (ub[nb]) break;
+      if (nub > nb) break;
+      std::swap(ub[nub], ub[nb]);
+      std::swap(perm[nub], perm[nb]);
+    }
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < N; ++c) A(r, c) = A0(perm[r], perm[c]);
+    x->resize(N); w->resize(N);
+    int32_t ok = 0, pivots = 0;
+    const int max_piv = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
+    const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
+    egs_status st = egs_mixed_constraints_solve_limits(egs::DefaultContext(), N, A0.data(), b.data(), C.data(), l.data(), h.data(),
+                                                       /*bounds + block pivoting*/ 3, max_piv, max_sec, x->data(), w->data(), &ok, &pivots);
+    g_last_lcp_pivots = pivots;
+    if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
+    return ok != 0;
   }
   x->resize(N); w->resize(N);
   int32_t ok = 0, pivots = 0;
-  egs_status st = egs_mixed_constraints_solve(egs::DefaultContext(), N, A.data(), b.data(), C.data(), l.data(), h.data(),
-                                              /*bounds + block pivoting*/ 3, x->data(), w->data(), &ok, &pivots);
+  const int max_piv = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
+  const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
+  egs_status st = egs_mixed_constraints_solve_limits(egs::DefaultContext(), N, A.data(), b.data(), C.data(), l.data(), h.data(),
+                                                     /*bounds + block pivoting*/ 3, max_piv, max_sec, x->data(), w->data(), &ok, &pivots);
+  g_last_lcp_pivots = pivots;
   if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
   return ok != 0;
 }
