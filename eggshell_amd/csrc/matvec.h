@@ -24,6 +24,7 @@ struct MatvecArgs {
   REAL *T;                   // [n_shared_entries][6]  J^T x of the sides on shared bodies
   REAL eps, scale;
   int32_t accumulate;        // y += part instead of y = part
+  int32_t stream_nt;         // 1: J0 / J1 with non-temporal loads (EGS_MV_NT=0 turns it off)
 };
 
 // part: 1 = strict lower, 2 = strict upper, 4 = diagonal, 8 = the full product.

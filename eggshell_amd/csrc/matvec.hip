@@ -156,8 +156,9 @@ __global__ void __launch_bounds__(BLOCK) matvec_tile_kernel(const MatvecArgs<REA
       const int e = q * BLOCK + tid, c = e / 9, u = e - 9 * c;
       const int ci = s_cidx[c];
       const V2 z = {REAL(0), REAL(0)};
-      r0[q] = ci >= 0 ? g0[(size_t)ci * 9 + u] : z;
-      r1[q] = ci >= 0 ? g1[(size_t)ci * 9 + u] : z;
+      // J is read exactly once per product: streaming (non-temporal) loads keep it out of the caches' way
+      r0[q] = ci >= 0 ? (A.stream_nt ? __builtin_nontemporal_load(g0 + (size_t)ci * 9 + u) : g0[(size_t)ci * 9 + u]) : z;
+      r1[q] = ci >= 0 ? (A.stream_nt ? __builtin_nontemporal_load(g1 + (size_t)ci * 9 + u) : g1[(size_t)ci * 9 + u]) : z;
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {

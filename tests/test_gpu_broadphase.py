@@ -6,6 +6,7 @@ import pytest
 from scipy.spatial.transform import Rotation
 
 from eggshell_amd import scenes
+from oracle import oracle as orc
 from test_gpu_collide import reference_contacts
 
 pytestmark = pytest.mark.gpu
@@ -88,3 +89,30 @@ def test_edge_cases_fail_loudly_or_return_empty(ctx, monkeypatch, mode):
     assert len(g0) == 4 and (g0 == -1).all() and (g1 == 0).all()
     g0, g1, gd = ctx.update_contacts(sc["p"], sc["R"])                            # the context still works
     assert len(g0) == 48
+
+
+def test_more_than_64_partners_for_one_body(ctx):
+    """A big plate under 100 small boxes: body 0 has 100 candidate partners, more than the 64 the capped
+    candidate lists hold.  The reference (all pairs, ensembles.cc:462-477) has no such limit; the collider
+    falls back to an uncapped count -> scan -> fill pass and the contact list stays the reference's."""
+    n = 101
+    p = np.zeros((n, 3)); side = np.tile([0.3, 0.3, 0.3], (n, 1))
+    side[0] = [5.0, 5.0, 0.3]
+    p[0] = [0.0, 0.0, 0.149]
+    for k in range(100):
+        p[1 + k] = [-2.0 + 0.42 * (k % 10), -2.0 + 0.42 * (k // 10), 0.448]
+    R = np.tile(np.eye(3).reshape(9), (n, 1))
+    g0, g1, gd = ctx.update_contacts(p, R, side)
+    b0, b1, data = [], [], []
+    for b in range(n):
+        for c in orc.collide_box_ground(p[b], R[b], side[b]):
+            b0.append(-1); b1.append(b); data.append(c)
+    for i in range(n):
+        for j in range(i + 1, n):
+            cs, code = orc.collide_boxes(p[i], R[i], p[j], R[j], side[i], side[j])
+            keep = [cs[a] for a in range(len(cs)) if not any(np.linalg.norm(cs[b][:3] - cs[a][:3]) < 1e-6 for b in range(a))]
+            for c in keep:
+                b0.append(i); b1.append(j); data.append(c)
+    assert len(g0) == len(b0) == 4 + 400
+    assert np.array_equal(g0, np.array(b0, np.int32)) and np.array_equal(g1, np.array(b1, np.int32))
+    assert np.array_equal(gd, np.array(data).reshape(-1, 7))
