@@ -165,14 +165,15 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit):
     achieved = upd / (kernel_ms * 1e-3)
     mb = load_profile_json("microbench.json")
     base = kernel.split("(")[0]
-    key = {"tile_solve_kernel": "update_iso_w1_a1_ticks" if st.schedule & capi.SCHED_ISO else "update_reg_w1_a1_ticks"}.get(base)
-    t_upd_cycles, src = None, None
-    if mb and key and key in mb[0]:
-        t_upd_cycles, src = float(mb[0][key]), "%s:%s (one always-ready update, alone on a CU, shader cycles)" % (mb[1], key)
-    if t_upd_cycles is None:
-        # two LDS round trips + the dependent fp64 chain + the hand-off stores
-        t_upd_cycles, src = (300.0 if base == "quad_solve_kernel" else 560.0), "DESIGN.md section 5 estimate (no microbench.json for this kernel)"
-    t_upd = t_upd_cycles / (CLOCK_GHZ * 1e3)     # us
+    # t_update_min: ONE dependent constraint update of this kernel, hand-off included, measured on the real
+    # kernel with tools/gpu_time_chain.py (one body with 64 world contacts = a chain of 64 K totally ordered
+    # updates); patches and the all-global kernel are held against the in-LDS figure of their lane layout
+    fam = "quad" if base == "quad_solve_kernel" else ("tile_iso" if st.schedule & capi.SCHED_ISO else "tile_reg")
+    key = "chain_update_us_%s_%s" % (fam, prec)
+    if mb and key in mb[0]:
+        t_upd, src = float(mb[0][key]), "%s:%s (64 K totally ordered updates on the real kernel, hand-offs included)" % (mb[1], key)
+    else:   # ~140 fp64 instructions of one wavefront at ~6.8 cycles each
+        t_upd, src = (0.36 if fam == "quad" else 0.47), "DESIGN.md section 5 (no microbench.json)"
     tiles_cu = resident_tiles_per_cu(st, prec)
     n_tiles = max(st.n_tiles, 1)
     rounds = max(1, math.ceil(n_tiles / float(tiles_cu * N_CU)))
@@ -190,7 +191,10 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit):
         "note": "algorithmic_restream_gbs = updates/s x %d B (SURVEY 8d: a design that re-streams the system every sweep); "
                 "J blocks and accumulators stay in VGPRs/LDS across sweeps, so it is information, not a bound" % BYTES_PER_CONTACT_SWEEP[prec],
     }
-    tr = measured_traffic_per_contact(base)
+    if st.schedule & (capi.SCHED_QUAD_PATCHES | capi.SCHED_LANE_PATCHES | capi.SCHED_ALL_GLOBAL):
+        lat["note_patches"] = ("the bound counts every hand-off at the in-LDS latency; an island cut into patches also pays ~4 us of global "
+                               "memory at each patch switch of a body's constraint list (2-4 per body and sweep), DESIGN.md section 4")
+    tr = measured_traffic_per_contact(kernel) or (measured_traffic_per_contact(base) if kernel == base else None)
     hbm = None
     if tr:
         traffic = tr[0] * m
@@ -390,10 +394,11 @@ def c5_leg(ctx, cpu_seconds):
     for N, mode, reps in ((2048, 2, 3), (512, 2, 3), (512, 0, 1), (256, 0, 1)):
         A, b, C, lo, hi = c5_problem(N)
         ok, x, w, piv = ctx.mixed_constraints_solve(A, b, C, lo, hi, use_bounds=mode)    # warm-up (code objects, buffers)
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        ms = float("inf")
+        for _ in range(reps):      # best of `reps`: each call allocates, uploads pageable memory, solves, downloads
+            t0 = time.perf_counter()
             ok, x, w, piv = ctx.mixed_constraints_solve(A, b, C, lo, hi, use_bounds=mode)
-        ms = (time.perf_counter() - t0) / reps * 1e3
+            ms = min(ms, (time.perf_counter() - t0) * 1e3)
         ne = int(C.sum()); ni = N - ne
         flops = ne ** 3 / 3.0 + 2.0 * ne * ne * ni + ni * ni * ne       # the Schur stage
         resid = float(np.abs(A @ x - b - w).max())

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
   case "$c" in
     stats)
-      timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-seconds 0 --legs matvec,single_pile,coupled > "$OUT/kt.log" 2>&1 || echo "stats failed"
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$R/bench.py" --steps 20 --warmup 5 --cpu-seconds 0 > "$OUT/kt.log" 2>&1 || echo "stats failed"
       ;;
     *)
       for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -30,6 +30,7 @@ def main():
     dir_f, dir_w, out = sys.argv[1:4]
     contacts = int(sys.argv[4]) if len(sys.argv) > 4 else 24 * 16384
     only = sys.argv[5] if len(sys.argv) > 5 else None     # merge just this kernel's figure into an existing file
+    store_as = sys.argv[6] if len(sys.argv) > 6 else only  # ... under this key (one kernel, two cases: "quad_solve_kernel(patches)")
     fetch, write = per_kernel(dir_f, "FETCH_SIZE"), per_kernel(dir_w, "WRITE_SIZE")
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
@@ -55,9 +56,9 @@ def main():
                                                if not k.startswith("__amd")}
     if only:   # one case of tools/pmc_case.py: keep the other kernels' figures of the file
         old = json.load(open(out)) if os.path.exists(out) else {"cases": {}, "hbm_bytes_per_contact_per_launch": {}}
-        old.setdefault("cases", {})[only] = {"contacts_per_launch": contacts, "kernel": kernels.get(only),
-                                             "bytes_per_contact": doc["hbm_bytes_per_contact_per_launch"].get(only)}
-        old["hbm_bytes_per_contact_per_launch"][only] = doc["hbm_bytes_per_contact_per_launch"].get(only)
+        old.setdefault("cases", {})[store_as] = {"contacts_per_launch": contacts, "kernel": kernels.get(only),
+                                                 "bytes_per_contact": doc["hbm_bytes_per_contact_per_launch"].get(only)}
+        old["hbm_bytes_per_contact_per_launch"][store_as] = doc["hbm_bytes_per_contact_per_launch"].get(only)
         old["command"] = ("rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 tools/pmc_case.py <case> (two separate "
                           "passes per case), summarised by tools/pmc_summary.py")
         old["correction"] = doc["correction"]
