@@ -17,6 +17,7 @@ the kernels the north star names, each with the physical bound that applies:
   single_pile   one C3 pile (the dependency chain of a pile: latency)
   matvec        the stand-alone block-sparse J M^-1 J^T product on C3 x batch
                 (the one kernel of the path that streams: HBM roofline)
+  c1            the Chain(8) ensemble of ensembles.cc (the reference's CPU-runnable case): latency only
   c2            256-body pile, 50 sweeps
   c4            1024 x 64-body ensembles, fp32
   coupled       ONE island of ~16k contacts (a running-bond wall): what a
@@ -142,7 +143,7 @@ def solve_kernel_name(st):
 def resident_tiles_per_cu(st, prec):
     """Workgroup tiles one CU keeps resident (register-limited)."""
     if st.schedule & capi.SCHED_QUAD:
-        return {64: 5, 128: 2, 256: 1}.get(st.tile_constraints, 1)      # 96 VGPRs, 4 lanes per constraint
+        return {64: 4, 128: 2, 256: 1}.get(st.tile_constraints, 1)      # 98 VGPRs (104 allocated): 4 wavefronts per SIMD
     if st.schedule & (capi.SCHED_QUAD_PATCHES | capi.SCHED_ALL_GLOBAL):
         return 1
     if st.schedule & capi.SCHED_LANE_PATCHES:
@@ -422,6 +423,51 @@ def c5_leg(ctx, cpu_seconds):
     return out
 
 
+def c1_leg(ctx, cpu_seconds):
+    """BASELINE config 1: the single Chain ensemble of ensembles.cc (8 bodies, 7 ball joints + the anchor),
+    fp64 -- the reference's own CPU-runnable case.  Through the GPU library: the iterative path with the
+    reference's constants (SOR, omega 1.5, tol 1e-9, at most 500 sweeps; x0 = rhs) and one step through the
+    dense path (ComputeVDot: dense J M^-1 J^T, condition estimate, MixedConstraintsSolver).  Latency only:
+    24 rows cannot fill a GPU."""
+    from oracle import oracle as orc
+    sc = scenes.chain(8)
+    pr, _ = build_problem(ctx, sc, capi.F64)
+    prm = capi.params(method=capi.SOR, max_iters=500, tol=1e-9, cfm=0.1)      # cfm 0.1 as the reference's tests (sparse_iterations.cc:305)
+    pr.assemble(1e-3, 0.2)
+    st = pr.solve(prm)
+    reps, t0 = 20, time.perf_counter()
+    for _ in range(reps):
+        st = pr.solve(prm)
+    ms_iter = (time.perf_counter() - t0) / reps * 1e3
+    ok, piv = pr.step_dense(1e-3, 0.2, 0.0)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ok, piv = pr.step_dense(1e-3, 0.2, 0.0)
+    ms_dense = (time.perf_counter() - t0) / reps * 1e3
+    pr.close()
+    out = {"workload": "Chain(8, anchor (0,0,2)): 8 bodies, 8 ball joints (7 + the anchor), 24 rows, dt = 1e-3",
+           "iterative": {"ms_per_solve": ms_iter, "sweeps": st.iterations, "residual": st.residual, "method": "SOR(1.5), tol 1e-9, cfm 0.1",
+                         "includes": "the reference's stopping loop (residual after every sweep), host-synchronous"},
+           "dense": {"ms_per_step": ms_dense, "ok": bool(ok), "pivots": int(piv),
+                     "includes": "assemble + dense system + MixedConstraintsSolver + velocity update, host-synchronous"}}
+    if cpu_seconds > 0:
+        J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+        s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+        rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, 1e-3, 0.2)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            x, it, res = orc.lit_iterate(s, rhs, 0.1, orc.SOR)
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms/solve", "literal_ms_per_solve": (time.perf_counter() - t0) / 50 * 1e3,
+                               "sweeps": it, "sample": "50 solves, oracle/sparse_literal.c (the reference's O(m^2) pair loops), 1 thread"}
+        t0 = time.perf_counter()
+        for _ in range(200):
+            x, a, it2, res = orc.fast_iterate(s, rhs, 0.1, orc.SOR)
+        out["cpu_baseline"]["fast_ms_per_solve"] = (time.perf_counter() - t0) / 200 * 1e3
+    return out
+
+
 def cpu_baseline(workload, budget_s):
     """Single-thread CPU port (oracle/, the fast O(nnz) sequential PGS in list order + assembly +
     velocity update) on ONE pile of the same workload."""
@@ -486,7 +532,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"], help="the headline workload (`value`)")
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
-    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c2,c4,coupled,c5,literal (1 GPU only)")
+    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal (1 GPU only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -504,7 +550,7 @@ def main():
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
     legs = set() if (args.legs == "none" or world > 1) else \
-        ({"single_pile", "matvec", "c2", "c4", "coupled", "c5", "literal"} if args.legs == "all" else set(args.legs.split(",")))
+        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal"} if args.legs == "all" else set(args.legs.split(",")))
 
     if args.workload == "c4":     # BASELINE config 4: 1024 ensembles sharded over the ranks
         seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
@@ -562,6 +608,8 @@ def main():
             extra["single_pile"] = leg_from_run(s1, args.steps, unit, "the headline workload with ONE pile on the GPU: the "
                                                 "dependency chain of a pile (latency); the >= 10x north-star target reads against this")
             s1["problem"].close()
+        if "c1" in legs:
+            extra["c1"] = c1_leg(ctx, args.cpu_seconds)
         if "c2" in legs and args.workload != "c2":
             s2 = run_piles(ctx, "c2", [1], method, args.steps, args.warmup)
             extra["c2"] = leg_from_run(s2, args.steps, "pile-steps/s", "BASELINE config 2: 256-body pile, 1024 contacts, 50 sweeps fp64")

@@ -155,3 +155,33 @@ def test_argument_errors(ctx):
         with pytest.raises(capi.EgsError):
             pr.matvec(np.zeros(3 * s.m), bad)
     pr.close()
+
+
+def test_edge_topologies(ctx):
+    """No constraints; a constraint with the world on both sides (only eps x survives, D = 0); one body
+    carrying 300 constraints (more than a tile: the body is shared by three tiles)."""
+    pr = capi.Problem(ctx, 3, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    pr.set_blocks(np.tile(np.eye(6).reshape(36), (3, 1)), np.zeros((0, 18)), np.zeros((0, 18)), np.zeros(0, np.uint8),
+                  np.zeros(0), np.zeros(0), np.zeros(0))
+    assert pr.matvec(np.zeros(0), FULL, EPS).shape == (0,)
+    pr.close()
+    rng = np.random.default_rng(8)
+    s, _ = random_system(rng, 4, 6)
+    b0, b1 = s.body0.copy(), s.body1.copy()
+    b0[2] = b1[2] = -1                                   # world on both sides
+    J0, J1 = s.J0.copy(), s.J1.copy()
+    J0[2] = 0.0; J1[2] = 0.0
+    s2 = orc.Sys(s.Minv, b0, b1, J0, J1, s.is_eq, s.lo, s.hi)
+    x = rng.uniform(-1, 1, 3 * s2.m)
+    check_all_parts(ctx, s2, x, dense=True)
+    y = ctx.matvec_blocks(s2.Minv, b0, b1, J0, J1, x, FULL, EPS)
+    assert np.array_equal(y[6:9], EPS * x[6:9])
+    m = 300
+    star = orc.Sys(s.Minv[:2], np.where(rng.uniform(size=m) < 0.5, -1, 1).astype(np.int32), np.zeros(m, np.int32),
+                   rng.uniform(-1, 1, (m, 18)), rng.uniform(-1, 1, (m, 18)), np.zeros(3 * m, np.uint8), np.zeros(3 * m), np.zeros(3 * m))
+    star.J0[star.body0 < 0] = 0.0
+    pl = capi.debug_matvec_plan(2, star.body0, star.body1, 128)
+    assert pl["n_tiles"] == 3 and pl["n_shared_bodies"] >= 1
+    check_all_parts(ctx, star, rng.uniform(-1, 1, 3 * m), lit=False)
+    xs = rng.uniform(-1, 1, 3 * m)
+    assert np.linalg.norm(ctx.matvec_blocks(star.Minv, star.body0, star.body1, star.J0, star.J1, xs, FULL, EPS) - orc.lit_JMJtX(star, xs, EPS)) < 1e-9 * 300
