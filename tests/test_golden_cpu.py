@@ -37,3 +37,19 @@ def test_oracle_matches_golden(path):
             xf = g["x_%s_10" % tag]
             ok = np.isfinite(xf)
             assert np.abs(xl[ok] - xf[ok]).max() <= 1e-9 * max(1.0, np.abs(xf[ok]).max())
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_matvec_twin_and_literal_match_golden(path):
+    """The matrix-free products of x = rhs: the O(nnz) twin reproduces the committed vectors bit for bit and
+    the literal O(m^2) restatement of CalculateSparse{Lx,Ux,Dx,JMJtX} agrees with them to the reference's 1e-9."""
+    g = np.load(path)
+    s = load_system(g)
+    cfm, scale, x = float(g["cfm"]), 1.0 / 1.5, g["rhs"]
+    for tag, parts in (("full", 8), ("L", 1), ("U", 2), ("D", 4), ("LU", 3), ("UD", 6), ("LD", 5)):
+        assert np.array_equal(orc.fast_matvec(s, x, parts, cfm, scale), g["mv_" + tag])
+    assert np.linalg.norm(g["mv_full"] - g["Ax_rhs"]) < 1e-9
+    Lx, Ux, Dx = orc.lit_Lx(s, x), orc.lit_Ux(s, x), orc.lit_Dx(s, x, cfm, scale)
+    assert np.array_equal(Lx, g["mvlit_L"]) and np.array_equal(Ux, g["mvlit_U"]) and np.array_equal(Dx, g["mvlit_D"])
+    for tag, want in (("L", Lx), ("U", Ux), ("D", Dx), ("LU", Lx + Ux), ("UD", Ux + Dx), ("LD", Lx + Dx)):
+        assert np.linalg.norm(g["mv_" + tag] - want) < 1e-9

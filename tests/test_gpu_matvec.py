@@ -185,3 +185,19 @@ def test_edge_topologies(ctx):
     check_all_parts(ctx, star, rng.uniform(-1, 1, 3 * m), lit=False)
     xs = rng.uniform(-1, 1, 3 * m)
     assert np.linalg.norm(ctx.matvec_blocks(star.Minv, star.body0, star.body1, star.J0, star.J1, xs, FULL, EPS) - orc.lit_JMJtX(star, xs, EPS)) < 1e-9 * 300
+
+
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_products(ctx, path):
+    """The committed golden vectors (tests/tools/make_golden.py): every product of x = rhs, bit for bit."""
+    g = np.load(path)
+    cfm, scale = float(g["cfm"]), 1.0 / 1.5
+    for tag, parts in (("full", FULL), ("L", L), ("U", U), ("D", D), ("LU", L | U), ("UD", U | D), ("LD", L | D)):
+        y = ctx.matvec_blocks(g["Minv"], g["body0"], g["body1"], g["J0"], g["J1"], g["rhs"], parts, cfm, scale)
+        assert np.array_equal(y, g["mv_" + tag]), tag

@@ -44,6 +44,13 @@ def scene_fixture(name, sc, dt, cfm):
 
 def solve_outputs(d, s, rhs, cfm):
     d["Ax_rhs"] = orc.lit_JMJtX(s, rhs, cfm)
+    # the matrix-free products of x = rhs (sparse_iterations_utils.cc:427-695): the O(nnz) twin in the
+    # kernels' operation order (what the GPU must reproduce bit for bit) and the literal O(m^2) algorithm
+    scale = 1.0 / 1.5
+    for tag, parts in (("full", 8), ("L", 1), ("U", 2), ("D", 4), ("LU", 3), ("UD", 6), ("LD", 5)):
+        d["mv_" + tag] = orc.fast_matvec(s, rhs, parts, cfm, scale)
+    d["mvlit_L"], d["mvlit_U"] = orc.lit_Lx(s, rhs), orc.lit_Ux(s, rhs)
+    d["mvlit_D"] = orc.lit_Dx(s, rhs, cfm, scale)
     for method, tag in ((0, "jacobi"), (1, "gs"), (2, "sor")):
         for K in SWEEPS:
             x, a, it, res = orc.fast_iterate(s, rhs, cfm, method, max_iters=K, tol=0.0)
