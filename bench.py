@@ -137,6 +137,8 @@ def solve_kernel_name(st):
         return "patch_solve_kernel"
     if st.schedule & capi.SCHED_ALL_GLOBAL:
         return "global_solve_kernel"
+    if st.schedule & capi.SCHED_STATIC:
+        return "step_solve_kernel"
     return "tile_solve_kernel"
 
 
@@ -155,7 +157,7 @@ def resident_tiles_per_cu(st, prec):
     return {64: 8, 128: 4, 256: 2, 512: 1}.get(st.tile_constraints, 1)   # 232 VGPRs: 2 wavefronts per SIMD
 
 
-def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit):
+def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit, case=None):
     """The bounds of one solve launch.  `roofline` (bound = latency): the launch cannot end before
     rounds x critical-path updates x t_update_min -- rounds = how often the CUs' resident tiles
     turn over, t_update_min = ONE always-ready constraint update of this kernel's instruction
@@ -170,32 +172,46 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit):
     # kernel with tools/gpu_time_chain.py (one body with 64 world contacts = a chain of 64 K totally ordered
     # updates); patches and the all-global kernel are held against the in-LDS figure of their lane layout
     fam = "quad" if base == "quad_solve_kernel" else ("tile_iso" if st.schedule & capi.SCHED_ISO else "tile_reg")
+    if base == "step_solve_kernel":     # static timetable: one update + one workgroup barrier per time step
+        fam = "step_iso" if st.schedule & capi.SCHED_ISO else "step_reg"
     key = "chain_update_us_%s_%s" % (fam, prec)
+    t_two = None
     if mb and key in mb[0]:
-        t_upd, src = float(mb[0][key]), "%s:%s (64 K totally ordered updates on the real kernel, hand-offs included)" % (mb[1], key)
+        t_upd, src = float(mb[0][key]), ("%s:%s (64 K totally ordered updates on the real kernel, hand-offs included; the faster of the "
+                                         "one-sided and the two-sided chain)" % (mb[1], key))
+        t_two = mb[0].get(key + "_two_sided")
     else:   # ~140 fp64 instructions of one wavefront at ~6.8 cycles each
         t_upd, src = (0.36 if fam == "quad" else 0.47), "DESIGN.md section 5 (no microbench.json)"
     tiles_cu = resident_tiles_per_cu(st, prec)
     n_tiles = max(st.n_tiles, 1)
     rounds = max(1, math.ceil(n_tiles / float(tiles_cu * N_CU)))
-    t_min_ms = rounds * crit[0] * t_upd * 1e-3
+    crit_updates, model = crit[0], "t_kernel >= rounds x critical_path x t_update_min"
+    if base == "step_solve_kernel":     # the timetable's own length: the x0 accumulation is a time slot of its own
+        crit_updates = crit[1] + crit[2] * sweeps
+        model = "t_kernel >= rounds x time_steps x t_step_min, time_steps = sweep_depth + per_body_period x sweeps"
+    t_min_ms = rounds * crit_updates * t_upd * 1e-3
     lat = {
         "bound": "latency", "unit": "constraint-updates/s", "achieved": achieved, "peak": upd / (t_min_ms * 1e-3),
         "frac": t_min_ms / kernel_ms, "traffic": None,
         "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches,
-        "model": "t_kernel >= rounds x critical_path x t_update_min",
+        "model": model,
         "rounds": rounds, "resident_tiles_per_cu": tiles_cu, "tiles": n_tiles,
-        "critical_path_updates": crit[0], "sweep_depth": crit[1], "per_body_period": crit[2],
+        "critical_path_updates": crit_updates, "sweep_depth": crit[1], "per_body_period": crit[2],
         "t_update_min_us": t_upd, "t_update_min_source": src,
         "achieved_fp64_tflops" if prec == "f64" else "achieved_fp32_tflops": achieved * FLOPS_PER_CONTACT_SWEEP / 1e12,
         "algorithmic_restream_gbs": achieved * BYTES_PER_CONTACT_SWEEP[prec] / 1e9,
         "note": "algorithmic_restream_gbs = updates/s x %d B (SURVEY 8d: a design that re-streams the system every sweep); "
                 "J blocks and accumulators stay in VGPRs/LDS across sweeps, so it is information, not a bound" % BYTES_PER_CONTACT_SWEEP[prec],
     }
+    if t_two:   # information: the same bound priced with body-body updates only (a pile has 15 of them per body-world one)
+        lat["t_update_two_sided_us"] = float(t_two)
+        lat["frac_two_sided_updates"] = rounds * crit_updates * float(t_two) * 1e-3 / kernel_ms
     if st.schedule & (capi.SCHED_QUAD_PATCHES | capi.SCHED_LANE_PATCHES | capi.SCHED_ALL_GLOBAL):
         lat["note_patches"] = ("the bound counts every hand-off at the in-LDS latency; an island cut into patches also pays ~4 us of global "
                                "memory at each patch switch of a body's constraint list (2-4 per body and sweep), DESIGN.md section 4")
-    tr = measured_traffic_per_contact(kernel) or (measured_traffic_per_contact(base) if kernel == base else None)
+    # counters are per workload (tools/pmc_case.py): "kernel(case)" if that case was measured, else the kernel's main case
+    tr = (measured_traffic_per_contact("%s(%s)" % (kernel, case)) if case else None) or measured_traffic_per_contact(kernel) \
+        or (measured_traffic_per_contact(base) if kernel == base else None)
     hbm = None
     if tr:
         traffic = tr[0] * m
@@ -257,7 +273,7 @@ def run_piles(ctx, workload, seeds, method, steps, warmup, torch=None, tdist=Non
     keep = (np.where(one["body0"] >= 0, one["body0"], one["body1"]) % col) == 0
     crit = sweep_critical_path(np.where(one["body0"][keep] >= 0, one["body0"][keep] // col, -1),
                                np.where(one["body1"][keep] >= 0, one["body1"][keep] // col, -1), sweeps)
-    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, prec, st, crit)
+    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, prec, st, crit, case="c4" if workload == "c4" else None)
     return dict(elapsed=elapsed, n=sc["p"].shape[0], m=m, sweeps=sweeps, prec=prec, dt=dt, stats=st, t_plan=t_plan,
                 roofline=lat, roofline_hbm=hbm, shape=(nx, ny, nz), problem=pr, scene=sc, piles=len(piles))
 

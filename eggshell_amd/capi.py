@@ -17,7 +17,7 @@ JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
 F64, F32 = 0, 1
 JOINT_BALL, CONTACT_BOX = 0, 1
 MV_LOWER, MV_UPPER, MV_DIAG, MV_FULL = 1, 2, 4, 8
-SCHED_QUAD, SCHED_ISO, SCHED_QUAD_PATCHES, SCHED_LANE_PATCHES, SCHED_ALL_GLOBAL = 1, 2, 4, 8, 16
+SCHED_QUAD, SCHED_ISO, SCHED_QUAD_PATCHES, SCHED_LANE_PATCHES, SCHED_ALL_GLOBAL, SCHED_STATIC = 1, 2, 4, 8, 16, 32
 
 # every symbol include/eggshell_amd.h declares
 EXPORTS = [
@@ -33,7 +33,7 @@ EXPORTS = [
     "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
-    "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule",
+    "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -387,6 +387,19 @@ def debug_plan_slots(n_bodies, body0, body1, tile_size=256):
     if st != OK:
         raise EgsError(st, "egs_debug_plan_slots failed")
     return dict(lane=out[0], slot0=out[1], slot1=out[2], tile_nslots=out[3])
+
+
+def debug_plan_timetable(n_bodies, body0, body1, tile_size=256):
+    """Host-only: per constraint its level in the list-order dependency DAG and the period / depth of
+    its tile's static timetable (see egs_debug_plan_timetable)."""
+    body0, body1 = _i32(body0), _i32(body1)
+    m = body0.shape[0]
+    out = [np.zeros(m, np.int32) for _ in range(3)]
+    st = load().egs_debug_plan_timetable(C.c_int32(n_bodies), C.c_int32(m), _p(body0), _p(body1), C.c_int32(tile_size),
+                                         *[_p(o) for o in out])
+    if st != OK:
+        raise EgsError(st, "egs_debug_plan_timetable failed")
+    return dict(level=out[0], period=out[1], depth=out[2])
 
 
 class World:

@@ -87,6 +87,22 @@ constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 
 // measured on MI355X -- one 1024-thread patch (4 lanes per constraint) or two 256-thread
 // patches (232 VGPRs) per CU.  A kernel change that lowers occupancy lowers the limit and the
 // island falls through to the next schedule instead of stalling.
+// The tile plan's GS / SOR sweep on its static timetable (step_solve.hip) or on tickets
+// (tile_solve_kernel)?  The timetable takes depth + P x sweeps barrier steps, P = the largest level
+// span of a body in a tile; the ticket sweep follows the true dependency chains, about
+// depth + (largest per-body count) x sweeps updates long.  Regular islands (piles of columns) have
+// P = the per-body count and the timetable wins (every lane due at a step shares ONE pass); an
+// irregular island can have spans far beyond its counts, then the tickets win.
+// EGS_STEP=0 / 1 forces one or the other.
+inline bool use_static_timetable(const Plan &pl, int sweeps) {
+  if (!pl.levels_ok || pl.n_tiles <= 0) return false;
+  const char *e = std::getenv("EGS_STEP");
+  if (e) return std::atoi(e) != 0;
+  const double fixed = (double)pl.max_depth + (double)pl.max_period * sweeps;
+  const double ticket = (double)pl.max_depth + (double)pl.max_cnt * sweeps;
+  return fixed <= 1.15 * ticket;
+}
+
 enum OversizeSchedule { kQuadPatches = 0, kLanePatches = 1, kAllGlobal = 2 };
 inline OversizeSchedule choose_oversize_schedule(int n_patch_tiles, int quad_per_cu, int patch_per_cu, int cu_count,
                                                  bool patches_enabled, bool quad_patches_enabled) {
@@ -177,6 +193,8 @@ struct egs_problem {
   std::vector<int32_t> h_body0, h_body1;
   // plan
   DevBuf<LaneDesc> lanes;
+  DevBuf<uint16_t> lane_level;           // static timetable of the tile plan (plan.h)
+  DevBuf<int32_t> tile_period, tile_depth;
   DevBuf<int32_t> tile_nslots, tile_slot_off, slot_body;
   // latency-optimised schedule (4 lanes per constraint, 64-constraint tiles);
   // used for GS/SOR when the problem is small and every island fits a tile
@@ -186,6 +204,7 @@ struct egs_problem {
   // forces the all-global kernel, EGS_QUAD_PATCH=0 the 1-lane patches) and how many workgroups the
   // all-global kernel's persistent grid may have: both from the runtime's occupancy of the kernels
   int last_iso = 0;            // the last tile launch used the isotropic-body variant
+  int last_static = 0;         // ... ran on the static timetable (step_solve.hip)
   int oversize = 2;            // OversizeSchedule
   int global_max_blocks = 1;
   DevBuf<LaneDesc> q_lanes;
@@ -388,8 +407,13 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
       launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
+    } else if (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)) {
+      a.lane_level = p->lane_level.p; a.tile_period = p->tile_period.p; a.tile_depth = p->tile_depth.p;
+      launch_step_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+      p->last_static = 1;
     } else {
       launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+      p->last_static = 0;
     }
   }
   if (patch && p->plan.block != 256)   // patch lanes are laid out for 256-thread workgroups
@@ -526,7 +550,7 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_tiles = pl.n_tiles;
   st->n_global = (int32_t)pl.global.size();
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
-  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0);
+  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0) | (!p->use_quad && p->last_static ? EGS_SCHED_STATIC : 0);
   if (!p->use_quad && !pl.global.empty())
     st->schedule |= p->oversize == kQuadPatches ? EGS_SCHED_QUAD_PATCHES : p->oversize == kLanePatches ? EGS_SCHED_LANE_PATCHES : EGS_SCHED_ALL_GLOBAL;
   st->tile_constraints = pl.block;
@@ -952,6 +976,9 @@ void ensure_tile_plan(egs_problem *p) {
   }
   const Plan &pl = p->plan;
   stage(p->ctx, p->lanes, pl.lanes);
+  stage(p->ctx, p->lane_level, pl.lane_level);
+  stage(p->ctx, p->tile_period, pl.tile_period);
+  stage(p->ctx, p->tile_depth, pl.tile_depth);
   stage(p->ctx, p->tile_nslots, pl.tile_nslots);
   stage(p->ctx, p->tile_slot_off, pl.tile_slot_off);
   stage(p->ctx, p->slot_body, pl.slot_body);
@@ -1567,6 +1594,31 @@ egs_status egs_debug_plan_slots(int32_t n, int32_t m, const int32_t *body0, cons
         if (slot0) slot0[d.cidx] = d.slot0;
         if (slot1) slot1[d.cidx] = d.slot1;
         if (tile_nslots) tile_nslots[d.cidx] = pl.tile_nslots[t];
+      }
+    return EGS_OK;
+  } catch (const std::exception &) {
+    return EGS_ERR_INVALID;
+  }
+}
+
+egs_status egs_debug_plan_timetable(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,
+                                    int32_t *level, int32_t *period, int32_t *depth) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
+  try {
+    const Plan pl = build_plan(n, m, body0, body1, tile_size);
+    if (!pl.levels_ok) return EGS_ERR_INVALID;
+    for (int i = 0; i < m; ++i) {
+      if (level) level[i] = -1;
+      if (period) period[i] = -1;
+      if (depth) depth[i] = -1;
+    }
+    for (int t = 0; t < pl.n_tiles; ++t)
+      for (int l = 0; l < pl.block; ++l) {
+        const LaneDesc &d = pl.lanes[(size_t)t * pl.block + l];
+        if (d.cidx < 0) continue;
+        if (level) level[d.cidx] = pl.lane_level[(size_t)t * pl.block + l];
+        if (period) period[d.cidx] = pl.tile_period[t];
+        if (depth) depth[d.cidx] = pl.tile_depth[t];
       }
     return EGS_OK;
   } catch (const std::exception &) {

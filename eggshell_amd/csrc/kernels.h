@@ -31,6 +31,11 @@ struct SolveArgs {
   REAL cfm, kscale;
   int32_t sweeps, resume, max_slots;
   uint32_t spin_limit;
+  // static timetable of the same sweep (step_solve.hip, plan.h): per lane its level, per tile the
+  // period P and the depth of the level DAG
+  const uint16_t *lane_level = nullptr;
+  const int32_t *tile_period = nullptr, *tile_depth = nullptr;
+  int32_t n_tiles = 0;
   int iso = 0;              // 1: every M^-1 block is diag(a,a,a,b,b,b): B is formed on the fly (tile kernel)
   // Per-sweep history (tolerance-terminated solves): x after sweep s and each body's
   // accumulator once its last constraint of sweep s has run, s = 1..sweeps of this launch.
@@ -82,6 +87,9 @@ template <typename REAL>
 void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
 // max_blocks: how many workgroups of the persistent grid may be launched (all must be resident)
+// the same GS / SOR sweep on the plan's static timetable: one workgroup barrier per time step, no tickets
+template <typename REAL>
+void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int block, hipStream_t s);
 template <typename REAL>
 void launch_global_solve(const GlobalArgs<REAL> &a, int max_blocks, hipStream_t s);
 // workgroups per CU the hardware keeps resident for the cross-workgroup kernels' exact

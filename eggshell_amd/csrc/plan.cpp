@@ -165,7 +165,9 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   if (recycle) {   // keep the storage, drop the contents
     plan = std::move(*recycle);
     plan.n_islands = plan.n_tiles = 0; plan.max_slots = 1; plan.max_cnt = 1;
-    plan.lanes.clear(); plan.tile_nslots.clear(); plan.tile_slot_off.clear(); plan.slot_body.clear();
+    plan.lanes.clear(); plan.lane_level.clear(); plan.tile_period.clear(); plan.tile_depth.clear();
+    plan.max_period = plan.max_depth = 1; plan.levels_ok = true;
+    plan.tile_nslots.clear(); plan.tile_slot_off.clear(); plan.slot_body.clear();
     plan.global.clear();
     plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0;
     plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear(); plan.patch_slot_body.clear();
@@ -247,6 +249,20 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   // wavefronts that take turns (EGS_LANE_ORDER=0 restores island-major order).
   std::vector<int32_t> phase(m, 0);
   int max_phase = 0;
+  // levels of the list-order dependency DAG (plan.h) and every body's span of levels
+  std::vector<int32_t> level(m, 0), first_lvl(n_bodies, -1), last_lvl(n_bodies, -1);
+  {
+    std::vector<int32_t> nxt(n_bodies, 0);
+    for (int i = 0; i < m; ++i) {
+      const int b0 = body0[i], b1 = body1[i];
+      int lv = 0;
+      if (b0 >= 0) lv = nxt[b0];
+      if (b1 >= 0) lv = std::max(lv, nxt[b1]);
+      level[i] = lv;
+      for (int b : {b0, b1})
+        if (b >= 0) { nxt[b] = lv + 1; if (first_lvl[b] < 0) first_lvl[b] = lv; last_lvl[b] = lv; }
+    }
+  }
   {
     const char *env = std::getenv("EGS_LANE_ORDER");
     const bool by_phase = !(env && std::atoi(env) == 0);
@@ -301,6 +317,9 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   LaneDesc idle{};
   idle.cidx = -1;
   plan.lanes.assign((size_t)plan.n_tiles * block, idle);
+  plan.lane_level.assign((size_t)plan.n_tiles * block, 0);
+  plan.tile_period.assign(plan.n_tiles, 1);
+  plan.tile_depth.assign(plan.n_tiles, 1);
   plan.tile_nslots.assign(plan.n_tiles, 1);
   plan.tile_slot_off.assign(plan.n_tiles, 0);
   std::vector<int32_t> lane_fill(plan.n_tiles, 0);
@@ -330,6 +349,11 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     d.pos1 = (uint16_t)pos1[i];
     d.cnt1 = (uint16_t)(b1 >= 0 ? cnt[b1] : 0);
     plan.lanes[(size_t)tile * block + l] = d;
+    plan.lane_level[(size_t)tile * block + l] = (uint16_t)std::min(level[i], 65535);
+    if (level[i] > 65535) plan.levels_ok = false;
+    plan.tile_depth[tile] = std::max(plan.tile_depth[tile], level[i] + 1);
+    for (int b : {b0, b1})
+      if (b >= 0) plan.tile_period[tile] = std::max(plan.tile_period[tile], last_lvl[b] - first_lvl[b] + 1);
     if (colour) {
       const int li = l & 31;
       const int where = (l >> 5) << 2 | ((li < 4 || (li >= 12 && li < 16) || (li >= 20 && li < 28)) ? 0 : 2);
@@ -450,6 +474,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     plan.tile_slot_off[t] = off;
     off += plan.tile_nslots[t];
     plan.max_slots = std::max(plan.max_slots, plan.tile_nslots[t]);
+    plan.max_period = std::max(plan.max_period, plan.tile_period[t]);
+    plan.max_depth = std::max(plan.max_depth, plan.tile_depth[t]);
   }
   plan.slot_body.assign((size_t)off, -1);   // slot 0 of every tile = the world
   for (int b = 0; b < n_bodies; ++b)

@@ -38,6 +38,16 @@ struct Plan {
   int n_islands = 0, n_tiles = 0, max_slots = 1;
   int max_cnt = 1;                    // largest per-body constraint count (ticket period)
   std::vector<LaneDesc> lanes;        // n_tiles * block
+  // Static time-stepped schedule of the same sweep (step_solve.hip).  level = depth of the constraint in
+  // the list-order dependency DAG of one sweep (a constraint comes after the previous constraint of each
+  // of its bodies).  With P >= every body's level span (last level - first level + 1) the update of
+  // sweep s may run at time level + P * (s - 1): per body the times increase in list order and the next
+  // sweep's first update comes after this sweep's last, which is all the sweep order asks for.
+  std::vector<uint16_t> lane_level;   // per lane of `lanes`
+  std::vector<int32_t> tile_period;   // per tile: largest body span in the tile (P above)
+  std::vector<int32_t> tile_depth;    // per tile: largest level + 1
+  int max_period = 1, max_depth = 1;
+  bool levels_ok = true;              // false if a level does not fit 16 bits
   std::vector<int32_t> tile_nslots;   // per tile, slots in use (slot 0 = world)
   std::vector<int32_t> tile_slot_off; // per tile, offset into slot_body
   std::vector<int32_t> slot_body;     // slot -> global body index (-1 for slot 0)

@@ -90,7 +90,9 @@ typedef enum {
   EGS_SCHED_ISO = 2,           /* tile_solve_kernel, isotropic-body variant (no stored M^-1 J^T) */
   EGS_SCHED_QUAD_PATCHES = 4,  /* oversize islands: body patches on the 4-lane kernel */
   EGS_SCHED_LANE_PATCHES = 8,  /* oversize islands: body patches on the 1-lane kernel */
-  EGS_SCHED_ALL_GLOBAL = 16    /* oversize islands: the all-global kernel */
+  EGS_SCHED_ALL_GLOBAL = 16,   /* oversize islands: the all-global kernel */
+  EGS_SCHED_STATIC = 32        /* step_solve_kernel: the tile plan's sweep on its static timetable
+                                  (one workgroup barrier per time step) instead of tickets */
 } egs_schedule_flags;
 
 void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */
@@ -354,6 +356,16 @@ egs_status egs_debug_plan_slots(int32_t n_bodies, int32_t m, const int32_t *body
                                 const int32_t *body1, int32_t tile_size,
                                 int32_t *lane, int32_t *slot0, int32_t *slot1,
                                 int32_t *tile_nslots);
+
+/* The static timetable of the same schedule (step_solve.hip): constraint c
+ * runs its update of sweep s at time step level[c] + period * s of its tile, level = depth in the
+ * list-order dependency DAG of one sweep (sparse_iterations_utils.cc:159-243: a constraint reads
+ * what the previous constraint of each of its bodies wrote), period = the largest level span of a
+ * body in the tile, depth = levels in the tile.  Arrays [m] (period / depth: the values of the
+ * constraint's tile), may be NULL; -1 on the cross-workgroup path.                              */
+egs_status egs_debug_plan_timetable(int32_t n_bodies, int32_t m, const int32_t *body0,
+                                    const int32_t *body1, int32_t tile_size,
+                                    int32_t *level, int32_t *period, int32_t *depth);
 
 /* Which kernel takes islands larger than a workgroup in a GS / SOR solve (host only, the
  * chooser the library itself uses): 0 = body patches on the 4-lanes-per-constraint kernel,

@@ -1,6 +1,6 @@
 """GPU (-m gpu): parity AT THE BENCH CONFIGURATION.  bench.py's headline is 24 C3 piles in one
-problem with the default switches, which runs tile_solve_kernel's isotropic-body variant
-(256-constraint tiles, three per CU); 6 piles run the regular tile kernel.  Every pile of the batch
+problem with the default switches, which runs the static-timetable kernel's isotropic-body variant
+(step_solve_kernel, 256-constraint tiles, three per CU); 6 piles run the regular variant.  Every pile of the batch
 must have the bits of its own sequential list-order solve (oracle fast O(nnz) port), and the
 kernel's epilogue w = A lambda - rhs must equal the literal-product residual element by element."""
 import os
@@ -26,11 +26,12 @@ def test_bench_config_parity(ctx, batch):
     pr.step(dt, 0.2, prm)
     st = pr.stats()
     assert st.status == capi.OK and st.n_global == 0 and st.n_islands == 256 * batch
-    default_switches = not any(k in os.environ for k in ("EGS_QUAD", "EGS_ISO", "EGS_TILE"))   # tests/tools/env_matrix.sh forces others
+    default_switches = not any(k in os.environ for k in ("EGS_QUAD", "EGS_ISO", "EGS_TILE", "EGS_STEP"))   # tests/tools/env_matrix.sh forces others
     if default_switches:
         assert st.reserved == 0 and not (st.schedule & capi.SCHED_QUAD)
         if batch == 24:    # the kernel bench.py's `value` is measured on
             assert st.schedule & capi.SCHED_ISO and st.tile_constraints == 256 and st.n_tiles == 1536
+            assert st.schedule & capi.SCHED_STATIC       # regular columns: the static timetable (step_solve.hip)
     lam, wres, acc = pr.lambda_(), pr.wres(), pr.accumulators()
     J0, J1, is_eq, lo, hi, rhs, err = pr.blocks()
     Minv, f_ext = bench.host_mass_and_force(sc)

@@ -44,14 +44,17 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
         cfm = float(rng.choice([0.0, 0.01, 0.3]))
         xf, af, _, _ = orc.fast_iterate(s, rhs, cfm, method, max_iters=K, tol=0.0)
         xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, cfm, method, max_iters=K)
-        for quad, patch, qpatch in (("1", "1", "1"), ("0", "1", "0"), ("0", "0", "1")):
+        # 4-lane tiles; 1-lane tiles on tickets; 1-lane tiles on the static timetable (step_solve.hip), with either oversize path
+        for quad, patch, qpatch, step in (("1", "1", "1", "0"), ("0", "1", "0", "0"), ("0", "1", "0", "1"), ("0", "0", "1", "1")):
+            monkeypatch.setenv("EGS_STEP", step)
             monkeypatch.setenv("EGS_QUAD", quad)
             monkeypatch.setenv("EGS_PATCH", patch)
             monkeypatch.setenv("EGS_QUAD_PATCH", qpatch)
             x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64, dirty=case % 2 == 1)
             assert st.status == capi.OK
-            assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, quad, patch)
-        monkeypatch.setenv("EGS_QUAD", "1"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
+            assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, quad, patch, step)
+        # the remaining legs alternate between the 4-lane kernel and the static timetable
+        monkeypatch.setenv("EGS_QUAD", "1" if case % 2 == 0 else "0"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
         if case % 5 == 0 and cfm > 0:     # the reference's stopping loop (recorded chunks on the device)
             tol, cap, every = float(rng.choice([1e-3, 1e-7])), int(rng.integers(1, 150)), int(rng.choice([1, 1, 3]))
             pr = capi.Problem(ctx, s.n, s.body0, s.body1)

@@ -1,7 +1,9 @@
 """GPU (-m gpu): the device-side ordering waits are bounded and a timed-out wait is never
 silent (EGS_ERR_STALL).  EGS_DEBUG_SPIN_LIMIT=1 forces the time-out: the flag is sticky, so
 an asynchronous step reports it at the next synchronising call, and a world refuses to
-integrate the bodies with the lambda of a stalled solve."""
+integrate the bodies with the lambda of a stalled solve.  The static-timetable kernel
+(step_solve.hip) has no waits at all, so these tests pin the ticket kernels (EGS_STEP=0);
+the last test checks that the timetable is indifferent to the spin limit."""
 import numpy as np
 import pytest
 
@@ -19,6 +21,12 @@ def pile_problem(ctx, shape=(3, 3, 6)):
     pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
     pr.set_constraints(sc["kind"], sc["data"])
     return sc, Minv, f_ext, pr
+
+
+@pytest.fixture(autouse=True)
+def ticket_kernels(request, monkeypatch):
+    if "timetable" not in request.node.name:
+        monkeypatch.setenv("EGS_STEP", "0")
 
 
 @pytest.mark.parametrize("quad", ["0", "1"])
@@ -76,3 +84,18 @@ def test_world_does_not_integrate_a_stalled_solve(ctx, monkeypatch):
     w.step(5e-3, 0.2, prm)                        # and the world goes on
     assert not np.array_equal(w.bodies()[0], before[0])
     w.close()
+
+
+def test_timetable_kernel_has_no_waits_to_time_out(ctx, monkeypatch):
+    monkeypatch.setenv("EGS_QUAD", "0")
+    monkeypatch.setenv("EGS_STEP", "1")
+    sc, Minv, f_ext, pr = pile_problem(ctx)
+    prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=20, tol=0.0, cfm=0.01)
+    st = pr.step(5e-3, 0.2, prm, want_stats=True)
+    assert st.schedule & capi.SCHED_STATIC
+    good = pr.lambda_()
+    monkeypatch.setenv("EGS_DEBUG_SPIN_LIMIT", "1")
+    st = pr.step(5e-3, 0.2, prm, want_stats=True)
+    assert st.status == capi.OK and st.schedule & capi.SCHED_STATIC
+    assert np.array_equal(pr.lambda_(), good)
+    pr.close()

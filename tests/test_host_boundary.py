@@ -204,3 +204,44 @@ def test_oversize_schedule_chooser_follows_the_occupancy():
     assert ch(100, 1, 2, cu_count=64) == 1 and ch(130, 1, 2, cu_count=64) == 2   # fewer CUs (partitioned device)
     assert ch(10, 1, 2, patches=False) == 2 and ch(10, 1, 2, quad_patches=False) == 1
     assert ch(0, 1, 2) == 2
+
+
+def _timetable_is_list_order(body0, body1, tt, sweeps=3):
+    """Replay the timetable of step_solve.hip on the host: at time step level + period * s the
+    constraint runs sweep s.  Per body, the (sweep, list index) pairs must come in exactly the
+    order of the sequential list-order sweeps, with no two of them in one time step."""
+    m = body0.shape[0]
+    on_tile = tt["level"] >= 0
+    events = {}
+    for c in np.nonzero(on_tile)[0]:
+        for s in range(sweeps):
+            t = int(tt["level"][c]) + int(tt["period"][c]) * s
+            assert t < int(tt["depth"][c]) + int(tt["period"][c]) * (sweeps - 1)       # inside the kernel's loop bound
+            for b in {int(body0[c]), int(body1[c])} - {-1}:
+                events.setdefault(b, []).append((t, s, int(c)))
+    for b, ev in events.items():
+        ev.sort()
+        times = [e[0] for e in ev]
+        assert len(set(times)) == len(times), "two updates of body %d in one time step" % b
+        assert [(e[1], e[2]) for e in ev] == sorted((e[1], e[2]) for e in ev), "body %d out of list order" % b
+    return int(on_tile.sum())
+
+
+def test_static_timetable_reproduces_list_order():
+    # regular columns: period = per-body count (8), depth = 64
+    sc = scenes.box_stack(4, 4, 16, jitter=1e-3, seed=3)
+    tt = capi.debug_plan_timetable(sc["p"].shape[0], sc["body0"], sc["body1"], 256)
+    assert _timetable_is_list_order(sc["body0"], sc["body1"], tt) == sc["body0"].shape[0]
+    assert tt["period"].max() == 8 and tt["depth"].max() == 64
+    # ragged random graphs, world sides, repeated pairs, every tile size
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        n = int(rng.integers(1, 40)); m = int(rng.integers(1, 300))
+        b1 = rng.integers(0, n, m).astype(np.int32)
+        b0 = np.where(rng.random(m) < 0.3, -1, rng.integers(0, n, m)).astype(np.int32)
+        b0 = np.where(b0 == b1, -1, b0).astype(np.int32)
+        for tile in (64, 128, 256, 512):
+            tt = capi.debug_plan_timetable(n, b0, b1, tile)
+            _timetable_is_list_order(b0, b1, tt)
+            on = tt["level"] >= 0
+            assert np.all(tt["period"][on] <= tt["depth"][on]) and np.all(tt["period"][on] >= 1)
