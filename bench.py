@@ -130,7 +130,7 @@ def sweep_critical_path(body0, body1, sweeps):
 
 def solve_kernel_name(st):
     if st.schedule & capi.SCHED_QUAD:
-        return "quad_solve_kernel"
+        return "step_quad_kernel" if st.schedule & capi.SCHED_STATIC else "quad_solve_kernel"
     if st.schedule & capi.SCHED_QUAD_PATCHES:
         return "quad_solve_kernel(patches)"
     if st.schedule & capi.SCHED_LANE_PATCHES:
@@ -174,6 +174,8 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit, case=None)
     fam = "quad" if base == "quad_solve_kernel" else ("tile_iso" if st.schedule & capi.SCHED_ISO else "tile_reg")
     if base == "step_solve_kernel":     # static timetable: one update + one workgroup barrier per time step
         fam = "step_iso" if st.schedule & capi.SCHED_ISO else "step_reg"
+    if base == "step_quad_kernel":
+        fam = "stepq"
     key = "chain_update_us_%s_%s" % (fam, prec)
     t_two = None
     if mb and key in mb[0]:
@@ -181,12 +183,12 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit, case=None)
                                          "one-sided and the two-sided chain)" % (mb[1], key))
         t_two = mb[0].get(key + "_two_sided")
     else:   # ~140 fp64 instructions of one wavefront at ~6.8 cycles each
-        t_upd, src = (0.36 if fam == "quad" else 0.47), "DESIGN.md section 5 (no microbench.json)"
+        t_upd, src = (0.36 if fam in ("quad", "stepq") else 0.47), "DESIGN.md section 5 (no microbench.json)"
     tiles_cu = resident_tiles_per_cu(st, prec)
     n_tiles = max(st.n_tiles, 1)
     rounds = max(1, math.ceil(n_tiles / float(tiles_cu * N_CU)))
     crit_updates, model = crit[0], "t_kernel >= rounds x critical_path x t_update_min"
-    if base == "step_solve_kernel":     # the timetable's own length: the x0 accumulation is a time slot of its own
+    if base in ("step_solve_kernel", "step_quad_kernel"):     # the timetable's own length: the x0 accumulation is a time slot of its own
         crit_updates = crit[1] + crit[2] * sweeps
         model = "t_kernel >= rounds x time_steps x t_step_min, time_steps = sweep_depth + per_body_period x sweeps"
     t_min_ms = rounds * crit_updates * t_upd * 1e-3

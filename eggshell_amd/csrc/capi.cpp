@@ -208,6 +208,8 @@ struct egs_problem {
   int oversize = 2;            // OversizeSchedule
   int global_max_blocks = 1;
   DevBuf<LaneDesc> q_lanes;
+  DevBuf<uint16_t> q_lane_level;         // static timetable of the 4-lane plan
+  DevBuf<int32_t> q_tile_period, q_tile_depth;
   DevBuf<int32_t> q_tile_nslots, q_tile_slot_off, q_slot_body;
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
   DevBuf<GlobalDesc> gcons;
@@ -359,6 +361,7 @@ template <typename REAL>
 void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweeps, int resume) {
   egs_context *ctx = p->ctx;
   const bool quad = p->use_quad && method != EGS_JACOBI;
+  p->last_static = 0;
   if (!quad) ensure_tile_plan(p);
   const bool patch = !quad && method != EGS_JACOBI && p->plan.n_patch_tiles > 0 && p->oversize != kAllGlobal;
   record_kernel_event(ctx, true);
@@ -406,7 +409,14 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     p->last_iso = quad ? 0 : a.iso;
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
-      launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
+      if (use_static_timetable(p->planq, sweeps)) {
+        a.lane_level = p->q_lane_level.p; a.tile_period = p->q_tile_period.p; a.tile_depth = p->q_tile_depth.p;
+        launch_step_quad<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
+        p->last_static = 1;
+      } else {
+        launch_quad_solve<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
+        p->last_static = 0;
+      }
     } else if (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)) {
       a.lane_level = p->lane_level.p; a.tile_period = p->tile_period.p; a.tile_depth = p->tile_depth.p;
       launch_step_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
@@ -550,7 +560,7 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_tiles = pl.n_tiles;
   st->n_global = (int32_t)pl.global.size();
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
-  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0) | (!p->use_quad && p->last_static ? EGS_SCHED_STATIC : 0);
+  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0) | (p->last_static ? EGS_SCHED_STATIC : 0);
   if (!p->use_quad && !pl.global.empty())
     st->schedule |= p->oversize == kQuadPatches ? EGS_SCHED_QUAD_PATCHES : p->oversize == kLanePatches ? EGS_SCHED_LANE_PATCHES : EGS_SCHED_ALL_GLOBAL;
   st->tile_constraints = pl.block;
@@ -1041,6 +1051,9 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
         const Plan &pq = p->planq;
         p->use_quad = true;
         stage(p->ctx, p->q_lanes, pq.lanes);
+        stage(p->ctx, p->q_lane_level, pq.lane_level);
+        stage(p->ctx, p->q_tile_period, pq.tile_period);
+        stage(p->ctx, p->q_tile_depth, pq.tile_depth);
         stage(p->ctx, p->q_tile_nslots, pq.tile_nslots);
         stage(p->ctx, p->q_tile_slot_off, pq.tile_slot_off);
         stage(p->ctx, p->q_slot_body, pq.slot_body);

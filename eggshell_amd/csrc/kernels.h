@@ -86,10 +86,13 @@ void launch_mass_times_force(int n, const double *Minv, const double *f_ext, dou
 template <typename REAL>
 void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
                        int block, hipStream_t s);
-// max_blocks: how many workgroups of the persistent grid may be launched (all must be resident)
 // the same GS / SOR sweep on the plan's static timetable: one workgroup barrier per time step, no tickets
 template <typename REAL>
 void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int block, hipStream_t s);
+// ... and the 4-lanes-per-constraint schedule on the same timetable (quad_solve.hip)
+template <typename REAL>
+void launch_step_quad(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s);
+// max_blocks: how many workgroups of the persistent grid may be launched (all must be resident)
 template <typename REAL>
 void launch_global_solve(const GlobalArgs<REAL> &a, int max_blocks, hipStream_t s);
 // workgroups per CU the hardware keeps resident for the cross-workgroup kernels' exact

@@ -369,6 +369,191 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   }
 }
 
+
+__device__ __forceinline__ void load3(unsigned acc_addr, double (&a)[3]) {
+  asm volatile(
+      "ds_read_b64 %0, %3\n\t"
+      "ds_read_b64 %1, %3 offset:8\n\t"
+      "ds_read_b64 %2, %3 offset:16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]) : "v"(acc_addr) : "memory");
+}
+__device__ __forceinline__ void load3(unsigned acc_addr, float (&a)[3]) {
+  asm volatile(
+      "ds_read_b32 %0, %3\n\t"
+      "ds_read_b32 %1, %3 offset:4\n\t"
+      "ds_read_b32 %2, %3 offset:8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]) : "v"(acc_addr) : "memory");
+}
+
+// The 4-lanes-per-constraint sweep on the STATIC TIMETABLE of step_solve.hip (plan.h: level, period,
+// depth): constraint c runs its update of sweep s at time step level(c) + P * s, one workgroup barrier
+// per step, no tickets and no polling.  Same lane layout, same arithmetic and same bits as
+// quad_solve_kernel; what goes away is the ticket round trip through LDS on the critical path of a
+// dependent update (0.36 us -> see profiles/r02/microbench.json: chain_update_us_stepq_*).
+template <typename REAL, int METHOD, int QT, bool HIST>
+__global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  REAL *s_acc = reinterpret_cast<REAL *>(smem);
+
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int q = tid & 3, side = q >> 1, half = q & 1;
+  const int nslots = A.tile_nslots[tile];
+  const int32_t *slot_body = A.slot_body + A.tile_slot_off[tile];
+  for (int s = tid; s < nslots; s += 4 * QT) {
+    const int body = slot_body[s];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_acc[s * 6 + k] = (A.resume && body >= 0) ? A.acc[(size_t)body * 6 + k] : REAL(0);
+  }
+
+  const LaneDesc d = A.lanes[(size_t)tile * QT + (tid >> 2)];
+  const bool active = d.cidx >= 0;
+  const int slot = side ? d.slot1 : d.slot0;
+  const bool has = active && slot != 0;            // this lane's body is a real body
+  const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
+  REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
+  const int level = A.lane_level[(size_t)tile * QT + (tid >> 2)];
+  const int P = A.tile_period[tile], depth = A.tile_depth[tile];
+
+  REAL Jh[9], Bh[9], Dl[3], inv[3], rhs[3], lo[3], hi[3], x[3];
+  bool eq[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { Jh[k] = REAL(0); Bh[k] = REAL(0); }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { Dl[r] = inv[r] = rhs[r] = lo[r] = hi[r] = x[r] = REAL(0); eq[r] = true; }
+  if (active) {
+    const size_t c = (size_t)d.cidx;
+    if (has) {
+      const REAL *J = (side ? A.J1 : A.J0) + c * 18 + 3 * half;
+      const REAL *B = (side ? A.wsB1 : A.wsB0) + c * 18 + 9 * half;  // rows 3*half .. 3*half+2 of the 6x3
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Jh[3 * r + k] = J[6 * r + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Bh[k] = B[k];
+    }
+    const REAL *D = A.wsD + c * 9;
+    if (METHOD == 1) { Dl[0] = D[3]; Dl[1] = D[6]; Dl[2] = D[7]; }   // D10, D20, D21
+    else { Dl[0] = D[1]; Dl[1] = D[2]; Dl[2] = D[5]; }               // D01, D02, D12
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      inv[r] = A.wsInv[c * 3 + r];
+      rhs[r] = A.rhs[c * 3 + r];
+      lo[r] = A.lo[c * 3 + r];
+      hi[r] = A.hi[c * 3 + r];
+      eq[r] = A.is_eq[c * 3 + r] != 0;
+      clamp_bounds(eq[r], lo[r], hi[r]);
+      x[r] = A.resume ? A.x[c * 3 + r] : rhs[r];
+    }
+  }
+  // length of the tile's timetable (step_solve.hip: timetable_end)
+  int t_end;
+  if (METHOD == 2) t_end = (A.resume ? 0 : depth) + (A.sweeps >= 1 ? depth + P * (A.sweeps - 1) : 0);
+  else { const int n_phases = A.sweeps + (A.resume ? 0 : 1); t_end = n_phases >= 1 ? depth + P * (n_phases - 1) : 0; }
+  __syncthreads();
+
+  const unsigned acc_addr = lds_addr(my_acc);
+  const bool last_of_body = ((METHOD == 2) ? cnt - 1u - pos : pos) == cnt - 1u;
+  int sweep = A.resume ? 1 : 0;
+  const int t0 = (METHOD == 2 && !A.resume) ? depth : 0;       // backward sweeps start after the forward accumulation
+  int due = (METHOD == 2 && A.resume) ? depth - 1 - level : level;
+  if (!active || sweep > A.sweeps) due = 0x7fffffff;
+  for (int t = 0; t < t_end; ++t) {
+    if (due == t) {
+      REAL a[3];
+      load3(acc_addr, a);
+      REAL dx[3] = {REAL(0), REAL(0), REAL(0)};
+      if (sweep == 0) {   // accumulators from x0 = rhs (sparse_iterations.cc:202)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dx[r] = x[r];
+      } else {
+        REAL res[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          REAL p = Jh[3 * r] * a[0];
+          p = tfma(Jh[3 * r + 1], a[1], p);
+          p = tfma(Jh[3 * r + 2], a[2], p);
+          const REAL full = tfma(A.cfm, x[r], quad_sum(p));
+          res[r] = rhs[r] - full;
+        }
+        if (METHOD == 1) {
+          REAL t0r = res[0];
+          REAL xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
+          dx[0] = xn - x[0]; x[0] = xn;
+          REAL t1 = tfma(-Dl[0], dx[0], res[1]);
+          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+          dx[1] = xn - x[1]; x[1] = xn;
+          REAL t2 = tfma(-Dl[1], dx[0], res[2]);
+          t2 = tfma(-Dl[2], dx[1], t2);
+          xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+          dx[2] = xn - x[2]; x[2] = xn;
+        } else {
+          REAL t2 = res[2];
+          REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+          dx[2] = xn - x[2]; x[2] = xn;
+          REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
+          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+          dx[1] = xn - x[1]; x[1] = xn;
+          REAL t0r = tfma(-Dl[1], dx[2], res[0]);                // D02
+          t0r = tfma(-Dl[0], dx[1], t0r);                        // D01
+          xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
+          dx[0] = xn - x[0]; x[0] = xn;
+        }
+      }
+      REAL an[3] = {REAL(0), REAL(0), REAL(0)};
+      if (has) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          REAL u = tfma(Bh[3 * k + 0], dx[0], a[k]);
+          u = tfma(Bh[3 * k + 1], dx[1], u);
+          an[k] = tfma(Bh[3 * k + 2], dx[2], u);
+        }
+        store3(acc_addr, an);
+      }
+      if (HIST && sweep >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
+        if (q == 0) {
+          REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
+          hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+        }
+        if (has && last_of_body) {   // this was the body's last update of the sweep
+          const int body = slot_body[slot];
+          REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
+          ha[0] = an[0]; ha[1] = an[1]; ha[2] = an[2];
+        }
+      }
+      due = (METHOD == 2 && sweep == 0) ? t0 + (depth - 1 - level) : due + P;
+      if (++sweep > A.sweeps) due = 0x7fffffff;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's accumulator stores have landed
+    __builtin_amdgcn_s_barrier();
+  }
+
+  if (active) {  // lambda and w = A x - rhs with the final accumulators
+    REAL a[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] = my_acc[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      REAL p = Jh[3 * r] * a[0];
+      p = tfma(Jh[3 * r + 1], a[1], p);
+      p = tfma(Jh[3 * r + 2], a[2], p);
+      const REAL w = tfma(A.cfm, x[r], quad_sum(p)) - rhs[r];
+      if (q == 0) {
+        A.x[(size_t)d.cidx * 3 + r] = x[r];
+        A.wres[(size_t)d.cidx * 3 + r] = w;
+      }
+    }
+  }
+  for (int s = tid + 1; s < nslots; s += 4 * QT) {
+    const int body = slot_body[s];
+    if (body < 0) continue;   // unused slot number
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.acc[(size_t)body * 6 + k] = s_acc[s * 6 + k];
+  }
+}
+
 }  // namespace
 
 template <typename REAL>
@@ -428,5 +613,29 @@ template void launch_quad_solve<double>(const SolveArgs<double> &, int, int, int
 template void launch_quad_solve<float>(const SolveArgs<float> &, int, int, int, hipStream_t);
 template void launch_quad_patch_solve<double>(const SolveArgs<double> &, int, int, uint32_t *, hipStream_t);
 template void launch_quad_patch_solve<float>(const SolveArgs<float> &, int, int, uint32_t *, hipStream_t);
+
+template <typename REAL>
+void launch_step_quad(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s) {
+  if (n_tiles <= 0) return;
+  const size_t lds = (size_t)a.max_slots * 6 * sizeof(REAL);
+  const bool hist = a.hist_x != nullptr;
+#define EGS_SQLAUNCH(METHOD, QT, HIST) \
+  hipLaunchKernelGGL((step_quad_kernel<REAL, METHOD, QT, HIST>), dim3(n_tiles), dim3(4 * QT), lds, s, a)
+  if (tile_size == 64) {
+    if (method == 1) { if (hist) EGS_SQLAUNCH(1, 64, true); else EGS_SQLAUNCH(1, 64, false); }
+    else { if (hist) EGS_SQLAUNCH(2, 64, true); else EGS_SQLAUNCH(2, 64, false); }
+  } else if (tile_size == 128) {
+    if (method == 1) { if (hist) EGS_SQLAUNCH(1, 128, true); else EGS_SQLAUNCH(1, 128, false); }
+    else { if (hist) EGS_SQLAUNCH(2, 128, true); else EGS_SQLAUNCH(2, 128, false); }
+  } else if (tile_size == 256) {
+    if (method == 1) { if (hist) EGS_SQLAUNCH(1, 256, true); else EGS_SQLAUNCH(1, 256, false); }
+    else { if (hist) EGS_SQLAUNCH(2, 256, true); else EGS_SQLAUNCH(2, 256, false); }
+#undef EGS_SQLAUNCH
+  } else {
+    throw std::invalid_argument("launch_step_quad: tile size must be 64, 128 or 256");
+  }
+}
+template void launch_step_quad<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
+template void launch_step_quad<float>(const SolveArgs<float> &, int, int, int, hipStream_t);
 
 }  // namespace egs

@@ -44,8 +44,8 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
         cfm = float(rng.choice([0.0, 0.01, 0.3]))
         xf, af, _, _ = orc.fast_iterate(s, rhs, cfm, method, max_iters=K, tol=0.0)
         xo, ao, _, _ = orc.fast_iterate_f32(s, rhs, cfm, method, max_iters=K)
-        # 4-lane tiles; 1-lane tiles on tickets; 1-lane tiles on the static timetable (step_solve.hip), with either oversize path
-        for quad, patch, qpatch, step in (("1", "1", "1", "0"), ("0", "1", "0", "0"), ("0", "1", "0", "1"), ("0", "0", "1", "1")):
+        # 4-lane tiles on tickets / on the static timetable; 1-lane tiles on tickets / on the timetable (step_solve.hip), with either oversize path
+        for quad, patch, qpatch, step in (("1", "1", "1", "0"), ("1", "1", "1", "1"), ("0", "1", "0", "0"), ("0", "1", "0", "1"), ("0", "0", "1", "1")):
             monkeypatch.setenv("EGS_STEP", step)
             monkeypatch.setenv("EGS_QUAD", quad)
             monkeypatch.setenv("EGS_PATCH", patch)

@@ -49,10 +49,11 @@ def main():
     ctx = capi.Context(0)
     out = {}
     T, S = {"EGS_QUAD": "0", "EGS_STEP": "0"}, {"EGS_QUAD": "0", "EGS_STEP": "1"}   # ticket / static-timetable tile kernels
-    for name, env, prec in (("quad_f64", {"EGS_QUAD": "1"}, capi.F64), ("tile_reg_f64", dict(T, EGS_ISO="0"), capi.F64),
+    for name, env, prec in (("quad_f64", {"EGS_QUAD": "1", "EGS_STEP": "0"}, capi.F64), ("stepq_f64", {"EGS_QUAD": "1", "EGS_STEP": "1"}, capi.F64),
+                            ("stepq_f32", {"EGS_QUAD": "1", "EGS_STEP": "1"}, capi.F32), ("tile_reg_f64", dict(T, EGS_ISO="0"), capi.F64),
                             ("tile_iso_f64", dict(T, EGS_ISO="2"), capi.F64),
                             ("step_reg_f64", dict(S, EGS_ISO="0"), capi.F64), ("step_iso_f64", dict(S, EGS_ISO="2"), capi.F64),
-                            ("quad_f32", {"EGS_QUAD": "1"}, capi.F32), ("tile_reg_f32", dict(T, EGS_ISO="0"), capi.F32),
+                            ("quad_f32", {"EGS_QUAD": "1", "EGS_STEP": "0"}, capi.F32), ("tile_reg_f32", dict(T, EGS_ISO="0"), capi.F32),
                             ("tile_iso_f32", dict(T, EGS_ISO="2"), capi.F32),
                             ("step_reg_f32", dict(S, EGS_ISO="0"), capi.F32), ("step_iso_f32", dict(S, EGS_ISO="2"), capi.F32)):
         one, sched, tile = chain_time(ctx, env, prec, False)
