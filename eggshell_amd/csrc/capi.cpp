@@ -79,7 +79,11 @@ inline uint32_t spin_limit() {
   const long v = e ? std::atol(e) : 0;
   return v > 0 ? (uint32_t)v : kSpinLimitDefault;
 }
-constexpr int kQuadMaxConstraints = 65536;   // measured crossover: 4 C3 piles on the 4-lane schedule, 6 on the 1-lane one
+// The 4-lane schedule is the faster one while its tiles are all resident at once (one round): 5 x 64
+// constraints per CU in fp64 (94 VGPRs), 8 x 64 in fp32 -- hipOccupancyMaxActiveBlocksPerMultiprocessor
+// of the instantiation decides (C3 fp64: 4 piles 0.33 ms against 0.41 on the 1-lane schedule, 6 piles
+// 0.53 against 0.45).  No 4-lane plan is built at all beyond 8 tiles per CU.
+constexpr int kQuadTilesPerCuMax = 8;
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
 // Which kernel takes the oversize islands of a GS / SOR solve.  Patches wait on each other, so
 // all of a launch's patches must be co-resident: the limits are occupancy (workgroups per CU of
@@ -1042,12 +1046,18 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   {  // quad schedule: small problems whose islands all fit 64-constraint tiles
     const char *env = std::getenv("EGS_QUAD");
     const int force = env ? std::atoi(env) : -1;
-    if (m > 0 && force != 0 && (force == 1 || m <= kQuadMaxConstraints)) {
+    if (m > 0 && force != 0 && (force == 1 || (long)m <= 64L * kQuadTilesPerCuMax * p->ctx->cu_count)) {
       const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
       p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq);
-      if (p->planq.global.empty()) {
+      bool one_round = true;
+      if (force != 1 && p->planq.global.empty()) {
+        const size_t qlds = (size_t)p->planq.max_slots * 6 * p->real_size();
+        const int occ = p->precision == EGS_F32 ? occupancy_step_quad<float>(p->planq.block, qlds) : occupancy_step_quad<double>(p->planq.block, qlds);
+        one_round = (long)p->planq.n_tiles <= (long)occ * p->ctx->cu_count;
+      }
+      if (p->planq.global.empty() && one_round) {
         const Plan &pq = p->planq;
         p->use_quad = true;
         stage(p->ctx, p->q_lanes, pq.lanes);

@@ -101,6 +101,7 @@ void launch_global_solve(const GlobalArgs<REAL> &a, int max_blocks, hipStream_t 
 template <typename REAL> int occupancy_global_solve();
 template <typename REAL> int occupancy_patch_solve(size_t lds_bytes);
 template <typename REAL> int occupancy_quad_patch_solve(size_t lds_bytes);
+template <typename REAL> int occupancy_step_quad(int tile_size, size_t lds_bytes);
 // w = A x - rhs for the constraints of a GlobalDesc list (after the last sweep)
 template <typename REAL>
 void launch_global_wres(const GlobalArgs<REAL> &a, hipStream_t s);

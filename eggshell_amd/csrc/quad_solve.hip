@@ -606,6 +606,18 @@ int occupancy_quad_patch_solve(size_t lds) {
 #undef EGS_OCC
   return best;
 }
+// workgroups of the 4-lane timetable kernel one CU keeps resident (tile_size constraints = 4 x as many threads)
+template <typename REAL>
+int occupancy_step_quad(int tile_size, size_t lds) {
+  int nb = 0;
+  hipError_t e = hipErrorInvalidValue;
+  if (tile_size == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 64, false>, 256, lds);
+  else if (tile_size == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 128, false>, 512, lds);
+  else if (tile_size == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 256, false>, 1024, lds);
+  return e == hipSuccess ? nb : 0;
+}
+template int occupancy_step_quad<double>(int, size_t);
+template int occupancy_step_quad<float>(int, size_t);
 template int occupancy_quad_patch_solve<double>(size_t);
 template int occupancy_quad_patch_solve<float>(size_t);
 
