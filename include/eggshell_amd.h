@@ -91,8 +91,8 @@ typedef enum {
   EGS_SCHED_QUAD_PATCHES = 4,  /* oversize islands: body patches on the 4-lane kernel */
   EGS_SCHED_LANE_PATCHES = 8,  /* oversize islands: body patches on the 1-lane kernel */
   EGS_SCHED_ALL_GLOBAL = 16,   /* oversize islands: the all-global kernel */
-  EGS_SCHED_STATIC = 32        /* step_solve_kernel: the tile plan's sweep on its static timetable
-                                  (one workgroup barrier per time step) instead of tickets */
+  EGS_SCHED_STATIC = 32        /* step_solve_kernel / step_quad_kernel (with EGS_SCHED_QUAD): the plan's sweep on
+                                  its static timetable (one workgroup barrier per time step) instead of tickets */
 } egs_schedule_flags;
 
 void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */
