@@ -66,55 +66,76 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   return __builtin_fma(y, t, y);
 }
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt, i.e. waits for the
+// acknowledgement of the global stores in flight; the column loop below stores one finished column per
+// step and has no reason to wait for it).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Diagonal block: L11 = chol(T[k0.., k0..+64)) and its inverse, one workgroup of
-// two wavefronts in lock step (one barrier per column), everything in registers:
-//   wavefront 0, lane i = row i of the block: right-looking Cholesky; column j,
-//     scaled by 1/sqrt(pivot), is published in LDS as soon as it is final;
-//   wavefront 1, lane c = column c of L11^-1: forward substitution L X = I fed
+// five wavefronts in lock step (one barrier per column), everything in registers:
+//   wavefronts 0..3, lane i = row i of the block, wavefront w holding the columns
+//     k = w mod 4 (16 registers): right-looking Cholesky; the owner of column j
+//     scales it by 1/sqrt(pivot) and publishes it in LDS, then every wavefront
+//     updates ITS columns with it (16 - j/4 fused multiply-adds instead of 63 - j:
+//     the column step is the pivot's own latency chain -- broadcast read, fma,
+//     readlane, 1/sqrt refinement, scale, publish, barrier -- and little else);
+//     a finished column goes to memory at once, so its register may be clobbered;
+//   wavefront 4, lane c = column c of L11^-1: forward substitution L X = I fed
 //     by those columns (row j of the inverse is complete after step j).
-// Both read the published column into registers first (LDS broadcasts, issued
-// back to back) and then run their 63-j fused multiply-adds.
 // The inverse turns the panel's triangular solve and the diagonal steps of the
 // back substitution into matrix products (chol_trsm_kernel, back_solve_kernel).
-__global__ void __launch_bounds__(128) chol_diag_kernel(double *T, int ld, int k0, double *inv, int *fail) {
+__global__ void __launch_bounds__(320) chol_diag_kernel(double *T, int ld, int k0, double *inv, int *fail) {
   __shared__ __attribute__((aligned(16))) double sCol[2][NB];
   __shared__ double sRinv[2];
-  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-  double a[NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < 4) {
+    double a[NB / 4];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = (role == 0 && c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (role == 0) {
-      double d = readlane_f64(a[j], j);
-      if (!(d > 0.0)) { bad = true; d = 1.0; }
-      const double rinv = rsqrt_refined(d);
-      const double l = (lane >= j) ? a[j] * rinv : 0.0;
-      a[j] = l;
-      sCol[j & 1][lane] = l;
-      if (lane == j) sRinv[j & 1] = rinv;
+    for (int m = 0; m < NB / 4; ++m) {
+      const int c = 4 * m + wave;
+      a[m] = (c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
     }
-    __syncthreads();
-    double col[NB];
+    bool bad = false;
 #pragma unroll
-    for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
-    if (role == 0) {
-      const double l = a[j];
+    for (int j = 0; j < NB; ++j) {
+      const int mo = j >> 2;
+      if (wave == (j & 3)) {   // this wavefront owns column j, final since the update of step j - 1
+        double d = readlane_f64(a[mo], j);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double rinv = rsqrt_refined(d);
+        const double l = (lane >= j) ? a[mo] * rinv : 0.0;
+        sCol[j & 1][lane] = l;
+        if (lane == j) sRinv[j & 1] = rinv;
+        if (lane >= j) T[(size_t)(k0 + lane) * ld + k0 + j] = l;
+      }
+      lds_barrier();
+      if (j + 1 < NB) {
+        const double lrow = sCol[j & 1][lane];           // this row's entry of column j
+        // columns 4 m + wave of the groups m >= j / 4: those <= j are finished and stored, the rest get step j
 #pragma unroll
-      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(-l, col[k], a[k]);
-    } else {
+        for (int m = mo; m < NB / 4; ++m) a[m] = __builtin_fma(-lrow, sCol[j & 1][4 * m + wave], a[m]);
+      }
+    }
+    if (bad && lane == 0) atomicOr(fail, 1);
+  } else {
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      lds_barrier();
       const double xj = (((lane == j) ? 1.0 : 0.0) - a[j]) * sRinv[j & 1];   // lanes c > j: exactly 0
       inv[j * NB + lane] = xj;
+      double col[NB];
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
 #pragma unroll
       for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(col[k], xj, a[k]);
     }
-  }
-  if (role == 0) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c <= lane) T[(size_t)(k0 + lane) * ld + k0 + c] = a[c];
-    if (bad && lane == 0) atomicOr(fail, 1);
   }
 }
 
@@ -684,7 +705,7 @@ inline int grid1(size_t n, int block = 256) {
 void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
   for (int k0 = 0; k0 < nf; k0 += NB) {
     double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(128), 0, s, T, ld, k0, inv_k, fail);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, ld, k0, inv_k, fail);
     const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
     if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, ld, nrows, k0, inv_k);
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
