@@ -395,11 +395,12 @@ def debug_plan_timetable(n_bodies, body0, body1, tile_size=256):
     body0, body1 = _i32(body0), _i32(body1)
     m = body0.shape[0]
     out = [np.zeros(m, np.int32) for _ in range(3)]
+    runs = C.c_int32(0)
     st = load().egs_debug_plan_timetable(C.c_int32(n_bodies), C.c_int32(m), _p(body0), _p(body1), C.c_int32(tile_size),
-                                         *[_p(o) for o in out])
+                                         *[_p(o) for o in out], C.byref(runs))
     if st != OK:
         raise EgsError(st, "egs_debug_plan_timetable failed")
-    return dict(level=out[0], period=out[1], depth=out[2])
+    return dict(level=out[0], period=out[1], depth=out[2], runs=bool(runs.value))
 
 
 class World:

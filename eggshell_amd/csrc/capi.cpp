@@ -102,8 +102,9 @@ inline bool use_static_timetable(const Plan &pl, int sweeps) {
   if (!pl.levels_ok || pl.n_tiles <= 0) return false;
   const char *e = std::getenv("EGS_STEP");
   if (e) return std::atoi(e) != 0;
-  const double fixed = (double)pl.max_depth + (double)pl.max_period * sweeps;
-  const double ticket = (double)pl.max_depth + (double)pl.max_cnt * sweeps;
+  const double grp = pl.runs ? 4.0 : 1.0;     // with runs the timetable counts groups of four updates (plan.h)
+  const double fixed = grp * ((double)pl.max_depth + (double)pl.max_period * sweeps);
+  const double ticket = grp * (double)pl.max_depth + (double)pl.max_cnt * sweeps;
   return fixed <= 1.15 * ticket;
 }
 
@@ -415,6 +416,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       launch_cons_prepare<REAL>(a, ctx->stream);
       if (use_static_timetable(p->planq, sweeps)) {
         a.lane_level = p->q_lane_level.p; a.tile_period = p->q_tile_period.p; a.tile_depth = p->q_tile_depth.p;
+        a.runs = p->planq.runs ? 1 : 0;
         launch_step_quad<REAL>(a, method, p->planq.n_tiles, p->planq.block, ctx->stream);
         p->last_static = 1;
       } else {
@@ -423,6 +425,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       }
     } else if (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)) {
       a.lane_level = p->lane_level.p; a.tile_period = p->tile_period.p; a.tile_depth = p->tile_depth.p;
+      a.runs = p->plan.runs ? 1 : 0;
       launch_step_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
       p->last_static = 1;
     } else {
@@ -1050,7 +1053,9 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
       const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
-      p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq);
+      // runs (plan.h) while there is about one 64-constraint tile per CU
+      p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq,
+                            (long)m <= 64L * p->ctx->cu_count);
       bool one_round = true;
       if (force != 1 && p->planq.global.empty()) {
         const size_t qlds = (size_t)p->planq.max_slots * 6 * p->real_size();
@@ -1625,11 +1630,12 @@ egs_status egs_debug_plan_slots(int32_t n, int32_t m, const int32_t *body0, cons
 }
 
 egs_status egs_debug_plan_timetable(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t tile_size,
-                                    int32_t *level, int32_t *period, int32_t *depth) {
+                                    int32_t *level, int32_t *period, int32_t *depth, int32_t *runs) {
   if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
   try {
-    const Plan pl = build_plan(n, m, body0, body1, tile_size);
+    const Plan pl = build_plan(n, m, body0, body1, tile_size, nullptr, tile_size == 0);
     if (!pl.levels_ok) return EGS_ERR_INVALID;
+    if (runs) *runs = pl.runs ? 1 : 0;
     for (int i = 0; i < m; ++i) {
       if (level) level[i] = -1;
       if (period) period[i] = -1;

@@ -158,7 +158,7 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
 }  // namespace
 
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
-                int block, Plan *recycle) {
+                int block, Plan *recycle, bool allow_runs) {
   if (n_bodies < 0 || m < 0 || block < 0 || block > 1024)
     throw std::invalid_argument("build_plan: bad sizes");
   Plan plan;
@@ -166,7 +166,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     plan = std::move(*recycle);
     plan.n_islands = plan.n_tiles = 0; plan.max_slots = 1; plan.max_cnt = 1;
     plan.lanes.clear(); plan.lane_level.clear(); plan.tile_period.clear(); plan.tile_depth.clear();
-    plan.max_period = plan.max_depth = 1; plan.levels_ok = true;
+    plan.max_period = plan.max_depth = 1; plan.levels_ok = true; plan.runs = false;
     plan.tile_nslots.clear(); plan.tile_slot_off.clear(); plan.slot_body.clear();
     plan.global.clear();
     plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0;
@@ -251,14 +251,27 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   int max_phase = 0;
   // levels of the list-order dependency DAG (plan.h) and every body's span of levels
   std::vector<int32_t> level(m, 0), first_lvl(n_bodies, -1), last_lvl(n_bodies, -1);
+  // runs (plan.h): every aligned group of four constraints joins the same two bodies
+  {
+    const char *env = std::getenv("EGS_RUNS");
+    // (4-lane plans and on request only: a group's four updates keep 1/4 of its wavefront's lanes busy, which
+    //  is fine where the chain latency sets the time and costs passes where throughput does -- one C3 pile
+    //  on the 4-lane kernel: 0.260 -> 0.216 ms, two piles 0.271 -> 0.276, four 0.328 -> 0.364; C3 x 24 on
+    //  the 1-lane kernel: 1.00 -> 1.25 ms)
+    bool runs = quad_plan && allow_runs && !(env && std::atoi(env) == 0) && m > 0 && m % 4 == 0;
+    for (int i = 0; runs && i < m; ++i)
+      if ((i & 3) != 0 && (body0[i] != body0[i - 1] || body1[i] != body1[i - 1])) runs = false;
+    plan.runs = runs;
+  }
+  const int grp = plan.runs ? 4 : 1;   // constraints per node of the level DAG
   {
     std::vector<int32_t> nxt(n_bodies, 0);
-    for (int i = 0; i < m; ++i) {
+    for (int i = 0; i < m; i += grp) {
       const int b0 = body0[i], b1 = body1[i];
       int lv = 0;
       if (b0 >= 0) lv = nxt[b0];
       if (b1 >= 0) lv = std::max(lv, nxt[b1]);
-      level[i] = lv;
+      for (int k = 0; k < grp; ++k) level[i + k] = lv;
       for (int b : {b0, b1})
         if (b >= 0) { nxt[b] = lv + 1; if (first_lvl[b] < 0) first_lvl[b] = lv; last_lvl[b] = lv; }
     }
@@ -274,9 +287,10 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
         if (body0[i] >= 0 && body_island[body0[i]] < 0) body_island[body0[i]] = cons_island[i];
         if (body1[i] >= 0 && body_island[body1[i]] < 0) body_island[body1[i]] = cons_island[i];
       }
+      // (with runs: in groups of four -- a body's constraints come in whole groups)
       for (int b = 0; b < n_bodies; ++b)
-        if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], cnt[b]);
-      for (int i = 0; i < m; ++i) {
+        if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], cnt[b] / grp);
+      for (int i = 0; i < m; i += grp) {
         const int b0 = body0[i], b1 = body1[i];
         int lv = 0;
         if (b0 >= 0) lv = last[b0];
@@ -284,7 +298,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
         if (b0 >= 0) last[b0] = lv + 1;
         if (b1 >= 0) last[b1] = lv + 1;
         const int ph = lv % isl_period[cons_island[i]];
-        phase[i] = ph;
+        for (int k = 0; k < grp; ++k) phase[i + k] = ph;
         max_phase = std::max(max_phase, ph);
       }
     }

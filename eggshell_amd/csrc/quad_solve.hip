@@ -28,16 +28,7 @@ namespace egs {
 
 namespace {
 
-// quad_perm DPP: value of lane (l ^ 1) / (l ^ 2) inside each group of 4 lanes
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
-template <int CTRL>
-__device__ __forceinline__ double dpp(double v) {
-  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
+// quad_perm DPP (solve_device.h: dpp<CTRL>): value of lane (l ^ 1) / (l ^ 2) inside each group of 4 lanes
 constexpr int kXor1 = 0xB1;  // quad_perm [1,0,3,2]
 constexpr int kXor2 = 0x4E;  // quad_perm [2,3,0,1]
 
@@ -392,7 +383,7 @@ __device__ __forceinline__ void load3(unsigned acc_addr, float (&a)[3]) {
 // per step, no tickets and no polling.  Same lane layout, same arithmetic and same bits as
 // quad_solve_kernel; what goes away is the ticket round trip through LDS on the critical path of a
 // dependent update (0.36 us -> see profiles/r02/microbench.json: chain_update_us_stepq_*).
-template <typename REAL, int METHOD, int QT, bool HIST>
+template <typename REAL, int METHOD, int QT, bool HIST, bool RUNS>
 __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
@@ -456,72 +447,103 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
 
   const unsigned acc_addr = lds_addr(my_acc);
   const bool last_of_body = ((METHOD == 2) ? cnt - 1u - pos : pos) == cnt - 1u;
+  const int run_pos = (tid >> 2) & 3;      // RUNS: this constraint's place in its group of four (plan.h)
   int sweep = A.resume ? 1 : 0;
   const int t0 = (METHOD == 2 && !A.resume) ? depth : 0;       // backward sweeps start after the forward accumulation
   int due = (METHOD == 2 && A.resume) ? depth - 1 - level : level;
   if (!active || sweep > A.sweeps) due = 0x7fffffff;
+
+  // one update of this lane's constraint: `an` = its quarter of the body's accumulator, in and out
+  auto update = [&](REAL (&an)[3]) {
+    REAL dx[3] = {REAL(0), REAL(0), REAL(0)};
+    if (sweep == 0) {   // accumulators from x0 = rhs (sparse_iterations.cc:202)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dx[r] = x[r];
+    } else {
+      REAL res[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        REAL p = Jh[3 * r] * an[0];
+        p = tfma(Jh[3 * r + 1], an[1], p);
+        p = tfma(Jh[3 * r + 2], an[2], p);
+        const REAL full = tfma(A.cfm, x[r], quad_sum(p));
+        res[r] = rhs[r] - full;
+      }
+      if (METHOD == 1) {
+        REAL t0r = res[0];
+        REAL xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
+        dx[0] = xn - x[0]; x[0] = xn;
+        REAL t1 = tfma(-Dl[0], dx[0], res[1]);
+        xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+        dx[1] = xn - x[1]; x[1] = xn;
+        REAL t2 = tfma(-Dl[1], dx[0], res[2]);
+        t2 = tfma(-Dl[2], dx[1], t2);
+        xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+        dx[2] = xn - x[2]; x[2] = xn;
+      } else {
+        REAL t2 = res[2];
+        REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+        dx[2] = xn - x[2]; x[2] = xn;
+        REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
+        xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+        dx[1] = xn - x[1]; x[1] = xn;
+        REAL t0r = tfma(-Dl[1], dx[2], res[0]);                // D02
+        t0r = tfma(-Dl[0], dx[1], t0r);                        // D01
+        xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
+        dx[0] = xn - x[0]; x[0] = xn;
+      }
+    }
+    if (has) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        REAL u = tfma(Bh[3 * k + 0], dx[0], an[k]);
+        u = tfma(Bh[3 * k + 1], dx[1], u);
+        an[k] = tfma(Bh[3 * k + 2], dx[2], u);
+      }
+    }
+    if (HIST && sweep >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
+      if (q == 0) {
+        REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
+        hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
+      }
+      if (has && last_of_body) {   // this was the body's last update of the sweep
+        const int body = slot_body[slot];
+        REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
+        ha[0] = an[0]; ha[1] = an[1]; ha[2] = an[2];
+      }
+    }
+  };
+
   for (int t = 0; t < t_end; ++t) {
     if (due == t) {
-      REAL a[3];
-      load3(acc_addr, a);
-      REAL dx[3] = {REAL(0), REAL(0), REAL(0)};
-      if (sweep == 0) {   // accumulators from x0 = rhs (sparse_iterations.cc:202)
+      REAL an[3];
+      load3(acc_addr, an);
+      if (!RUNS) {
+        update(an);
+        if (has) store3(acc_addr, an);
+      } else if (METHOD == 1 || t < t0) {
+        // the group's four updates in list order; the accumulator goes from lane to lane (row_shr:4 =
+        // the same quarter of the previous constraint), LDS sees the first read and the last write only
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dx[r] = x[r];
+        for (int sub = 0; sub < 4; ++sub) {
+          if (sub > 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) an[k] = dpp<0x114>(an[k]);
+          }
+          if (run_pos == sub) update(an);
+        }
+        if (has && run_pos == 3) store3(acc_addr, an);
       } else {
-        REAL res[3];
+        // backward sweep: the list, and the group, from its end (row_shl:4)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          REAL p = Jh[3 * r] * a[0];
-          p = tfma(Jh[3 * r + 1], a[1], p);
-          p = tfma(Jh[3 * r + 2], a[2], p);
-          const REAL full = tfma(A.cfm, x[r], quad_sum(p));
-          res[r] = rhs[r] - full;
-        }
-        if (METHOD == 1) {
-          REAL t0r = res[0];
-          REAL xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
-          dx[0] = xn - x[0]; x[0] = xn;
-          REAL t1 = tfma(-Dl[0], dx[0], res[1]);
-          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
-          dx[1] = xn - x[1]; x[1] = xn;
-          REAL t2 = tfma(-Dl[1], dx[0], res[2]);
-          t2 = tfma(-Dl[2], dx[1], t2);
-          xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
-          dx[2] = xn - x[2]; x[2] = xn;
-        } else {
-          REAL t2 = res[2];
-          REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
-          dx[2] = xn - x[2]; x[2] = xn;
-          REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
-          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
-          dx[1] = xn - x[1]; x[1] = xn;
-          REAL t0r = tfma(-Dl[1], dx[2], res[0]);                // D02
-          t0r = tfma(-Dl[0], dx[1], t0r);                        // D01
-          xn = project(tfma(t0r, inv[0], x[0]), lo[0], hi[0]);
-          dx[0] = xn - x[0]; x[0] = xn;
-        }
-      }
-      REAL an[3] = {REAL(0), REAL(0), REAL(0)};
-      if (has) {
+        for (int sub = 0; sub < 4; ++sub) {
+          if (sub > 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          REAL u = tfma(Bh[3 * k + 0], dx[0], a[k]);
-          u = tfma(Bh[3 * k + 1], dx[1], u);
-          an[k] = tfma(Bh[3 * k + 2], dx[2], u);
+            for (int k = 0; k < 3; ++k) an[k] = dpp<0x104>(an[k]);
+          }
+          if (run_pos == 3 - sub) update(an);
         }
-        store3(acc_addr, an);
-      }
-      if (HIST && sweep >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
-        if (q == 0) {
-          REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
-          hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
-        }
-        if (has && last_of_body) {   // this was the body's last update of the sweep
-          const int body = slot_body[slot];
-          REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
-          ha[0] = an[0]; ha[1] = an[1]; ha[2] = an[2];
-        }
+        if (has && run_pos == 0) store3(acc_addr, an);
       }
       due = (METHOD == 2 && sweep == 0) ? t0 + (depth - 1 - level) : due + P;
       if (++sweep > A.sweeps) due = 0x7fffffff;
@@ -611,9 +633,9 @@ template <typename REAL>
 int occupancy_step_quad(int tile_size, size_t lds) {
   int nb = 0;
   hipError_t e = hipErrorInvalidValue;
-  if (tile_size == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 64, false>, 256, lds);
-  else if (tile_size == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 128, false>, 512, lds);
-  else if (tile_size == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 256, false>, 1024, lds);
+  if (tile_size == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 64, false, false>, 256, lds);
+  else if (tile_size == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 128, false, false>, 512, lds);
+  else if (tile_size == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step_quad_kernel<REAL, 1, 256, false, false>, 1024, lds);
   return e == hipSuccess ? nb : 0;
 }
 template int occupancy_step_quad<double>(int, size_t);
@@ -631,8 +653,11 @@ void launch_step_quad(const SolveArgs<REAL> &a, int method, int n_tiles, int til
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * 6 * sizeof(REAL);
   const bool hist = a.hist_x != nullptr;
-#define EGS_SQLAUNCH(METHOD, QT, HIST) \
-  hipLaunchKernelGGL((step_quad_kernel<REAL, METHOD, QT, HIST>), dim3(n_tiles), dim3(4 * QT), lds, s, a)
+#define EGS_SQLAUNCH(METHOD, QT, HIST)                                                                           \
+  do {                                                                                                           \
+    if (a.runs) hipLaunchKernelGGL((step_quad_kernel<REAL, METHOD, QT, HIST, true>), dim3(n_tiles), dim3(4 * QT), lds, s, a); \
+    else hipLaunchKernelGGL((step_quad_kernel<REAL, METHOD, QT, HIST, false>), dim3(n_tiles), dim3(4 * QT), lds, s, a);       \
+  } while (0)
   if (tile_size == 64) {
     if (method == 1) { if (hist) EGS_SQLAUNCH(1, 64, true); else EGS_SQLAUNCH(1, 64, false); }
     else { if (hist) EGS_SQLAUNCH(2, 64, true); else EGS_SQLAUNCH(2, 64, false); }

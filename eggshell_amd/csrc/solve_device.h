@@ -308,6 +308,18 @@ __device__ __forceinline__ void store_tick(unsigned tick_addr, unsigned v) {
 }
 
 
+// DPP move: the value of another lane of the same row of 16 (quad_perm, row_shr:n = 0x110 + n,
+// row_shl:n = 0x100 + n); lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 template <typename T>
 __device__ __forceinline__ T gld(const T *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -362,10 +362,15 @@ egs_status egs_debug_plan_slots(int32_t n_bodies, int32_t m, const int32_t *body
  * list-order dependency DAG of one sweep (sparse_iterations_utils.cc:159-243: a constraint reads
  * what the previous constraint of each of its bodies wrote), period = the largest level span of a
  * body in the tile, depth = levels in the tile.  Arrays [m] (period / depth: the values of the
- * constraint's tile), may be NULL; -1 on the cross-workgroup path.                              */
+ * constraint's tile), may be NULL; -1 on the cross-workgroup path.
+ * tile_size = 0: the 4-lanes-per-constraint plan with its automatic tile size.
+ * *runs = 1 (4-lane plan only): every aligned group of four consecutive constraints joins the same two bodies (the four
+ * contact points of a box face) and is ONE node of the timetable: level / period / depth then count
+ * groups, and the group's four updates run back to back inside its time step, in list order
+ * (reversed in a backward sweep), handing the accumulators from lane to lane.                     */
 egs_status egs_debug_plan_timetable(int32_t n_bodies, int32_t m, const int32_t *body0,
                                     const int32_t *body1, int32_t tile_size,
-                                    int32_t *level, int32_t *period, int32_t *depth);
+                                    int32_t *level, int32_t *period, int32_t *depth, int32_t *runs);
 
 /* Which kernel takes islands larger than a workgroup in a GS / SOR solve (host only, the
  * chooser the library itself uses): 0 = body patches on the 4-lanes-per-constraint kernel,

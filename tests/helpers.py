@@ -133,3 +133,16 @@ def random_system(rng, n, m, world_frac=0.2, eq_frac=0.4, connected=False):
     lo[is_eq == 1] = 0.0; hi[is_eq == 1] = 0.0
     rhs = rng.uniform(-1, 1, 3 * m)
     return orc.Sys(Minv, body0, body1, J0, J1, is_eq, lo, hi), rhs
+
+
+def grouped_system(rng, s, rhs, rep=4):
+    """Every constraint of `s` `rep` times in a row with fresh J blocks, bounds and right-hand sides:
+    the shape of a box face's contact points (the 4-lane plan treats aligned groups of four as runs)."""
+    m = s.body0.shape[0] * rep
+    body0, body1 = np.repeat(s.body0, rep), np.repeat(s.body1, rep)
+    J0 = rng.uniform(-1, 1, (m, 18)); J1 = rng.uniform(-1, 1, (m, 18))
+    J0[body0 < 0] = 0.0; J1[body1 < 0] = 0.0
+    is_eq = np.repeat(s.is_eq.reshape(-1, 3), rep, axis=0).reshape(-1)
+    lo = np.repeat(s.lo.reshape(-1, 3), rep, axis=0).reshape(-1)
+    hi = np.repeat(s.hi.reshape(-1, 3), rep, axis=0).reshape(-1)
+    return orc.Sys(s.Minv, body0, body1, J0, J1, is_eq, lo, hi), rng.uniform(-1, 1, 3 * m)

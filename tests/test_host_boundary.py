@@ -212,11 +212,13 @@ def _timetable_is_list_order(body0, body1, tt, sweeps=3):
     order of the sequential list-order sweeps, with no two of them in one time step."""
     m = body0.shape[0]
     on_tile = tt["level"] >= 0
+    grp = 4 if tt["runs"] else 1     # runs: a time step holds the four updates of a group, in list order
     events = {}
     for c in np.nonzero(on_tile)[0]:
         for s in range(sweeps):
-            t = int(tt["level"][c]) + int(tt["period"][c]) * s
-            assert t < int(tt["depth"][c]) + int(tt["period"][c]) * (sweeps - 1)       # inside the kernel's loop bound
+            step = int(tt["level"][c]) + int(tt["period"][c]) * s
+            assert step < int(tt["depth"][c]) + int(tt["period"][c]) * (sweeps - 1)    # inside the kernel's loop bound
+            t = step * grp + (int(c) % grp)
             for b in {int(body0[c]), int(body1[c])} - {-1}:
                 events.setdefault(b, []).append((t, s, int(c)))
     for b, ev in events.items():
@@ -232,7 +234,13 @@ def test_static_timetable_reproduces_list_order():
     sc = scenes.box_stack(4, 4, 16, jitter=1e-3, seed=3)
     tt = capi.debug_plan_timetable(sc["p"].shape[0], sc["body0"], sc["body1"], 256)
     assert _timetable_is_list_order(sc["body0"], sc["body1"], tt) == sc["body0"].shape[0]
-    assert tt["period"].max() == 8 and tt["depth"].max() == 64
+    assert not tt["runs"] and tt["period"].max() == 8 and tt["depth"].max() == 64
+    # the 4-lane plan (tile size 0 = its automatic choice) groups the four contact points of a box face
+    tt = capi.debug_plan_timetable(sc["p"].shape[0], sc["body0"], sc["body1"], 0)
+    assert _timetable_is_list_order(sc["body0"], sc["body1"], tt) == sc["body0"].shape[0]
+    assert tt["runs"] and tt["period"].max() == 2 and tt["depth"].max() == 16
+    for c in range(0, sc["body0"].shape[0], 4):                                      # ... adjacent in their tile
+        assert len(set(tt["level"][c:c + 4])) == 1
     # ragged random graphs, world sides, repeated pairs, every tile size
     rng = np.random.default_rng(11)
     for trial in range(30):
@@ -240,8 +248,12 @@ def test_static_timetable_reproduces_list_order():
         b1 = rng.integers(0, n, m).astype(np.int32)
         b0 = np.where(rng.random(m) < 0.3, -1, rng.integers(0, n, m)).astype(np.int32)
         b0 = np.where(b0 == b1, -1, b0).astype(np.int32)
-        for tile in (64, 128, 256, 512):
-            tt = capi.debug_plan_timetable(n, b0, b1, tile)
-            _timetable_is_list_order(b0, b1, tt)
-            on = tt["level"] >= 0
-            assert np.all(tt["period"][on] <= tt["depth"][on]) and np.all(tt["period"][on] >= 1)
+        for rep in (1, 4):       # 4: every constraint four times in a row, as a box face's contact points -> runs
+            c0, c1 = np.repeat(b0, rep), np.repeat(b1, rep)
+            for tile in (0, 64, 128, 256, 512):
+                tt = capi.debug_plan_timetable(n, c0, c1, tile)
+                grouped = rep == 4 or (m % 4 == 0 and all(c0[i] == c0[i - 1] and c1[i] == c1[i - 1] for i in range(m) if i % 4))
+                assert tt["runs"] == (tile == 0 and grouped)
+                _timetable_is_list_order(c0, c1, tt)
+                on = tt["level"] >= 0
+                assert np.all(tt["period"][on] <= tt["depth"][on]) and np.all(tt["period"][on] >= 1)
