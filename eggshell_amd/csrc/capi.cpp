@@ -82,8 +82,9 @@ inline uint32_t spin_limit() {
 // The 4-lane schedule is the faster one while its tiles are all resident at once (one round): 5 x 64
 // constraints per CU in fp64 (94 VGPRs), 8 x 64 in fp32 -- hipOccupancyMaxActiveBlocksPerMultiprocessor
 // of the instantiation decides (C3 fp64: 4 piles 0.33 ms against 0.41 on the 1-lane schedule, 6 piles
-// 0.53 against 0.45).  No 4-lane plan is built at all beyond 8 tiles per CU.
-constexpr int kQuadTilesPerCuMax = 8;
+// 0.53 against 0.45).  No 4-lane plan is built at all beyond the register file's 5 (fp64) / 8 (fp32)
+// tiles per CU.
+inline int quad_tiles_per_cu_max(int precision) { return precision == EGS_F32 ? 8 : 5; }
 constexpr int kBigTileMinConstraints = 196608;   // 768 tiles of 256: from here 512-constraint tiles
 // Which kernel takes the oversize islands of a GS / SOR solve.  Patches wait on each other, so
 // all of a launch's patches must be co-resident: the limits are occupancy (workgroups per CU of
@@ -1049,7 +1050,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   {  // quad schedule: small problems whose islands all fit 64-constraint tiles
     const char *env = std::getenv("EGS_QUAD");
     const int force = env ? std::atoi(env) : -1;
-    if (m > 0 && force != 0 && (force == 1 || (long)m <= 64L * kQuadTilesPerCuMax * p->ctx->cu_count)) {
+    if (m > 0 && force != 0 && (force == 1 || (long)m <= 64L * quad_tiles_per_cu_max(p->precision) * p->ctx->cu_count)) {
       const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
