@@ -514,6 +514,39 @@ def cpu_baseline(workload, budget_s):
                       "port, gcc -O2, 1 thread, %.1f s" % (done, nx, ny, nz, s.m, sweeps, prec, el)}
 
 
+def cpu_baseline_threads(workload, budget_s, threads):
+    """The same port on `threads` host threads at once, one pile each (the oracle's C functions run
+    outside the GIL): a MEASURED multi-core figure for the cores this process may use."""
+    import threading
+    from oracle import oracle as orc
+    nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
+    counts, t_start = [0] * threads, time.perf_counter()
+
+    def worker(k):
+        sc = scenes.box_stack(nx, ny, nz, seed=k + 1)
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+        while time.perf_counter() - t_start < budget_s:
+            J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+            s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+            rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
+            if prec == "f32":
+                x = orc.fast_iterate_f32(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps)[0]
+            else:
+                x = orc.fast_iterate(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps, tol=0.0)[0]
+            orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
+            counts[k] += 1
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    el = time.perf_counter() - t_start
+    return {"value": sum(counts) / el, "unit": "ensemble-steps/s" if workload == "c4" else "pile-steps/s", "cores": threads,
+            "kind": "port", "sample": "%d steps on %d threads, one %dx%dx%d pile each, %.1f s (measured)" % (sum(counts), threads, nx, ny, nz, el)}
+
+
 def cpu_literal_baseline(budget_s):
     """SURVEY 8(d) baseline (i): the LITERAL O(m^2) restatement -- the reference's real cost, without its
     virtual calls and mallocs -- in full at C1 and C2, one sweep at C3 (extrapolated to 100)."""
@@ -656,6 +689,14 @@ def main():
                           "not measured" % cores}
             out["gpu_over_cpu"] = {"batched_vs_1_core": out["value"] / out["cpu_baseline"]["value"],
                                    "batched_vs_all_cores_ideal": out["value"] / (out["cpu_baseline"]["value"] * cores)}
+            try:
+                usable = len(os.sched_getaffinity(0))
+            except AttributeError:
+                usable = cores
+            nthr = max(1, min(16, usable))
+            if nthr > 1:     # measured on the cores this process may use (a GPU box gives 16 of the host's)
+                out["cpu_baseline_threads"] = cpu_baseline_threads(args.workload, min(6.0, args.cpu_seconds), nthr)
+                out["gpu_over_cpu"]["batched_vs_%d_threads_measured" % nthr] = out["value"] / out["cpu_baseline_threads"]["value"]
             if "single_pile" in out:
                 out["gpu_over_cpu"]["single_pile_vs_1_core"] = out["single_pile"]["value"] / out["cpu_baseline"]["value"]
             if "literal" in legs:
