@@ -1,22 +1,28 @@
-"""Tolerance-terminated solves (the reference's default: stop at 1e-9 or 500 sweeps, residual
-checked every sweep): wall time per solve and per sweep."""
-import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R)
-from eggshell_amd import capi, scenes
-import bench
+#!/usr/bin/env python3
+"""Time the reference's stopping loop (tolerance-terminated solve, residual after every sweep) on one C3 / C2
+pile: chunks of recorded sweeps on the device.  usage: gpu_time_tol.py [c3|c2] [cap=500]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from eggshell_amd import capi, scenes  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+cap = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+nx, ny, nz, sweeps, prec, dt = bench.WORKLOADS[wl]
 ctx = capi.Context(0)
-for name, sc, cfm in (("chain(8)", scenes.chain(8), 0.1), ("C2 pile", scenes.box_stack(8, 8, 4), 0.1),
-                      ("C3 pile", scenes.box_stack(16, 16, 16), 0.1)):
-    Minv, f_ext = bench.host_mass_and_force(sc)
-    pr = capi.Problem(ctx, sc["p"].shape[0], sc["body0"], sc["body1"])
-    pr.set_state(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext); pr.set_constraints(sc["kind"], sc["data"])
-    for every in (1, 8):
-        prm = capi.params(method=capi.SOR, max_iters=500, tol=1e-9, cfm=cfm, check_every=every)
-        pr.step(1e-3, 0.2, prm)
-        ctx.synchronize(); t = time.perf_counter(); N = 5
-        for _ in range(N): st = pr.step(1e-3, 0.2, prm, want_stats=True)
-        ctx.synchronize(); dt = (time.perf_counter() - t) / N
-        print(f"{name}: check_every={every}: {st.iterations} sweeps, residual {st.residual:.2e}, {dt*1e3:.2f} ms/solve, "
-              f"{dt*1e6/max(st.iterations,1):.1f} us/sweep", flush=True)
-    pr.close()
+sc = scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=1)
+pr, _ = bench.build_problem(ctx, sc, capi.F64)
+pr.assemble(dt, 0.2)
+prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=cap, tol=1e-9, cfm=0.01)
+st = pr.solve(prm)
+best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter(); st = pr.solve(prm); best = min(best, time.perf_counter() - t0)
+print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("EGS_")}, "workload": wl, "ms_per_solve": best * 1e3,
+                  "sweeps": st.iterations, "residual": st.residual, "schedule": st.schedule, "us_per_sweep": best * 1e6 / max(st.iterations, 1)}))
+pr.close(); ctx.close()
