@@ -163,6 +163,18 @@ int orc_mixed_constraints(int dim, const double *A, const double *b,
 
 /* ---- collision (collision.cc), used to build the synthetic contact sets -- */
 /* collision.cc:408-436. contacts: [<=8][7] = pos(3), normal(3), depth. */
+/* ---- toolkit/lcp.cc: incremental-factor box LCP (lcp_toolkit.c).  Row-major n x n, lower triangle only. */
+int otk_cholesky(double *L, int n);
+void otk_lsolve(const double *L, int n, int m, double *x);
+void otk_ltsolve(const double *L, int n, int m, double *x);
+void otk_lltsolve(const double *L, int n, int m, double *x);
+int otk_rank_update(double *L, int n, int i0, int p, const double *vec, double sigma, double *temp);
+int otk_add_cholesky_row(const double *A, int n, int m, double *L);
+int otk_swap_cholesky_rows(const double *A, int n, int i, int m, double *L, double *work);
+void otk_swap_rows_and_columns(double *A, int n, int i, int j, int *perm);
+int otk_box_dantzig(int n, double *A, const double *b, const double *lo, const double *hi,
+                    double *x, double *w, int *perm_out, int *pivots);
+
 int orc_collide_box_ground(const double c[3], const double R[9],
                            const double side[3], double *contacts);
 /* collision.cc:166-388. contacts [<=16][7]; code_out may be NULL. */

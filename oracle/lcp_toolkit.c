@@ -1,0 +1,256 @@
+/* lcp_toolkit.c -- TEST INFRASTRUCTURE ONLY (see egs_oracle.h): a plain-C restatement of the
+ * incremental-factor box LCP of the reference's toolkit/lcp.cc, the `lcp::SolveLCP` family SURVEY
+ * row a13 / f4 names:
+ *   Cholesky / LSolve / LTSolve / LLTSolve     toolkit/lcp.cc:46-72
+ *   RankUpdate                                 toolkit/lcp.cc:76-83  (Eigen internal, see below)
+ *   AddCholeskyRow                             toolkit/lcp.cc:91-102
+ *   SwapCholeskyRows                           toolkit/lcp.cc:110-157
+ *   MatrixPermutation::SwapRowsAndColumns      toolkit/lcp.cc:171-195 (lower triangle only)
+ *   SolveLCP_BoxDantzig                        toolkit/lcp.cc:444-619
+ * Matrices are row-major n x n with leading dimension n; like the reference, only the lower
+ * triangle (row >= column) of A and L is ever read or written.
+ *
+ * Third-party piece: RankUpdate calls Eigen::internal::llt_rank_update_lower (Eigen 3.3.8 / 3.3.9,
+ * pinned by the #error at toolkit/lcp.cc:41-43; Eigen is absent from /root/reference and from this
+ * image).  Its published algorithm for a general sigma is the one of Gill, Golub, Murray and
+ * Saunders, "Methods for modifying matrix factorizations" (1974), method C1, restated in
+ * otk_rank_update; Eigen's faster Givens variant for sigma > 0 gives the same factor up to rounding,
+ * which is all the reference's own tests ask of it (vs a refactorisation, 1e-9, toolkit/lcp.cc:
+ * 1051-1078).  Operation order inside the triangular solves and products is NOT Eigen's (blocked,
+ * vectorised, unknown); it is the plain column-oriented order written here, which the device code
+ * repeats so that pivot decisions agree.  Parity of this path is therefore pinned by the
+ * reference's property tests (restated in tests/test_oracle_lcp_toolkit.py), not by golden vectors. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "egs_oracle.h"
+
+#define AT(M, r, c) (M)[(size_t)(r) * n + (c)]
+
+/* in-place Cholesky of the lower triangle, column by column (toolkit/lcp.cc:46-48) */
+int otk_cholesky(double *L, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = AT(L, j, j);
+    for (int k = 0; k < j; ++k) d = d - AT(L, j, k) * AT(L, j, k);
+    if (!(d > 0.0)) return j + 1;
+    d = sqrt(d);
+    AT(L, j, j) = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = AT(L, i, j);
+      for (int k = 0; k < j; ++k) s = s - AT(L, i, k) * AT(L, j, k);
+      AT(L, i, j) = s / d;
+    }
+  }
+  return 0;
+}
+
+/* L y = b on the top-left m x m block, column-oriented (toolkit/lcp.cc:52-54) */
+void otk_lsolve(const double *L, int n, int m, double *x) {
+  for (int j = 0; j < m; ++j) {
+    x[j] = x[j] / AT(L, j, j);
+    for (int k = j + 1; k < m; ++k) x[k] = x[k] - AT(L, k, j) * x[j];
+  }
+}
+
+/* L' x = y on the top-left m x m block (toolkit/lcp.cc:58-62) */
+void otk_ltsolve(const double *L, int n, int m, double *x) {
+  for (int j = m - 1; j >= 0; --j) {
+    x[j] = x[j] / AT(L, j, j);
+    for (int k = 0; k < j; ++k) x[k] = x[k] - AT(L, j, k) * x[j];
+  }
+}
+
+void otk_lltsolve(const double *L, int n, int m, double *x) {   /* toolkit/lcp.cc:66-69 */
+  otk_lsolve(L, n, m, x);
+  otk_ltsolve(L, n, m, x);
+}
+
+/* rank-one modification of the p x p block of L at (i0, i0): L L' += sigma vec vec'
+ * (toolkit/lcp.cc:76-83 -> Eigen llt_rank_update_lower, general-sigma variant; `temp` = p doubles).
+ * Returns 0, or j + 1 if the modified matrix is not positive definite at column j. */
+int otk_rank_update(double *L, int n, int i0, int p, const double *vec, double sigma, double *temp) {
+  for (int k = 0; k < p; ++k) temp[k] = vec[k];
+  double beta = 1.0;
+  for (int j = 0; j < p; ++j) {
+    const double Ljj = AT(L, i0 + j, i0 + j);
+    const double dj = Ljj * Ljj;
+    const double wj = temp[j];
+    const double swj2 = sigma * (wj * wj);
+    const double gamma = dj * beta + swj2;
+    const double xx = dj + swj2 / beta;
+    if (!(xx > 0.0)) return j + 1;
+    const double nLjj = sqrt(xx);
+    AT(L, i0 + j, i0 + j) = nLjj;
+    beta = beta + swj2 / dj;
+    const double f0 = wj / Ljj, f1 = nLjj / Ljj, f2 = (gamma != 0.0) ? nLjj * sigma * wj / gamma : 0.0;
+    for (int k = j + 1; k < p; ++k) {
+      const double lk = AT(L, i0 + k, i0 + j);
+      temp[k] = temp[k] - f0 * lk;
+      if (gamma != 0.0) AT(L, i0 + k, i0 + j) = f1 * lk + f2 * temp[k];
+    }
+  }
+  return 0;
+}
+
+/* row m - 1 of L from the factor of the leading (m-1) x (m-1) block (toolkit/lcp.cc:91-102) */
+int otk_add_cholesky_row(const double *A, int n, int m, double *L) {
+  if (m == 1) {
+    if (!(AT(A, 0, 0) > 0.0)) return 1;
+    AT(L, 0, 0) = sqrt(AT(A, 0, 0));
+    return 0;
+  }
+  double *ell = &AT(L, m - 1, 0);          /* solved in place in the new row */
+  for (int k = 0; k < m - 1; ++k) ell[k] = AT(A, m - 1, k);
+  otk_lsolve(L, n, m - 1, ell);
+  double s = 0.0;
+  for (int k = 0; k < m - 1; ++k) s = s + ell[k] * ell[k];
+  const double d = AT(A, m - 1, m - 1) - s;
+  if (!(d > 0.0)) return m;
+  AT(L, m - 1, m - 1) = sqrt(d);
+  return 0;
+}
+
+/* L (m x m factor of A's leading block) -> (m-1) x (m-1) factor of A with row/column m - 1 moved to i
+ * (toolkit/lcp.cc:110-157); A itself is not changed.  work = 2 n doubles. */
+int otk_swap_cholesky_rows(const double *A, int n, int i, int m, double *L, double *work) {
+  if (m <= 1 || i == m - 1) return 0;
+  double *wq = work, *temp = work + n;
+  if (i == 0) {
+    for (int k = 0; k < m - 1; ++k) wq[k] = AT(A, m - 1, k) - AT(A, k, 0);
+    wq[0] = (AT(A, m - 1, m - 1) - AT(A, 0, 0)) * 0.5 + 1.0;
+    int r = otk_rank_update(L, n, 0, m - 1, wq, 0.5, temp);
+    if (r) return r;
+    wq[0] = (AT(A, m - 1, m - 1) - AT(A, 0, 0)) * 0.5 - 1.0;
+    return otk_rank_update(L, n, 0, m - 1, wq, -0.5, temp);
+  }
+  double *l1 = &AT(L, i, 0);               /* new row i of L, solved in place */
+  for (int k = 0; k < i; ++k) l1[k] = AT(A, m - 1, k);
+  otk_lsolve(L, n, i, l1);
+  double s = 0.0;
+  for (int k = 0; k < i; ++k) s = s + l1[k] * l1[k];
+  const double d = AT(A, m - 1, m - 1) - s;
+  if (!(d > 0.0)) return i + 1;
+  const double e = sqrt(d);
+  AT(L, i, i) = e;
+  const int p = m - 2 - i;
+  if (p > 0) {
+    for (int k = 0; k < p; ++k) wq[k] = AT(L, i + 1 + k, i);       /* the original l2 */
+    int r = otk_rank_update(L, n, i + 1, p, wq, 1.0, temp);
+    if (r) return r;
+    for (int k = 0; k < p; ++k) {
+      double t = 0.0;
+      for (int c = 0; c < i; ++c) t = t + AT(L, i + 1 + k, c) * l1[c];
+      const double v = (AT(A, m - 1, i + 1 + k) - t) / e;
+      AT(L, i + 1 + k, i) = v;
+      wq[k] = v;
+    }
+    r = otk_rank_update(L, n, i + 1, p, wq, -1.0, temp);
+    if (r) return r;
+  }
+  return 0;
+}
+
+/* A(i <-> j) touching the lower triangle only (toolkit/lcp.cc:171-195); perm maps current -> original */
+void otk_swap_rows_and_columns(double *A, int n, int i, int j, int *perm) {
+  if (i == j) return;
+  if (i > j) { int t = i; i = j; j = t; }
+  { int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+  for (int c = 0; c < i; ++c) { double t = AT(A, i, c); AT(A, i, c) = AT(A, j, c); AT(A, j, c) = t; }
+  for (int r = j + 1; r < n; ++r) { double t = AT(A, r, i); AT(A, r, i) = AT(A, r, j); AT(A, r, j) = t; }
+  for (int k = i + 1; k < j; ++k) { double t = AT(A, k, i); AT(A, k, i) = AT(A, j, k); AT(A, j, k) = t; }
+  { double t = AT(A, i, i); AT(A, i, i) = AT(A, j, j); AT(A, j, j) = t; }
+}
+
+static void swapd(double *v, int a, int b) { double t = v[a]; v[a] = v[b]; v[b] = t; }
+
+/* SolveLCP_BoxDantzig (toolkit/lcp.cc:444-619).  A (lower triangle) is permuted in place; perm_out[k] =
+ * original index of the final row k.  Requires lo <= 0 <= hi, lo < hi.  Returns 1 (the reference always
+ * returns true), 0 if a factor update meets a non-positive pivot, -1 on allocation failure.
+ * *pivots = steps of the inner loop. */
+int otk_box_dantzig(int n, double *A, const double *b, const double *lo_arg, const double *hi_arg,
+                    double *x_out, double *w_out, int *perm_out, int *pivots) {
+  double *buf = (double *)calloc((size_t)n * n + 10 * (size_t)n, sizeof(double));
+  int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  if (!buf || !perm) { free(buf); free(perm); return -1; }
+  double *L = buf, *x = L + (size_t)n * n, *w = x + n, *lo = w + n, *hi = lo + n, *dxS = hi + n, *dwNS = dxS + n,
+         *limit = dwNS + n, *v = limit + n, *work = v + n;   /* work: 2 n */
+  for (int i = 0; i < n; ++i) { lo[i] = lo_arg[i]; hi[i] = hi_arg[i]; perm[i] = i; }
+  int index = 0, steps = 0, ok = 1;
+  for (int i = 0; i < n && ok; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < i; ++k) s = s + AT(A, i, k) * x[k];
+    w[i] = s - b[i];
+    x[i] = 0.0;
+    if (w[i] == 0.0) continue;
+    if (lo[i] == 0.0 && w[i] >= 0.0) continue;
+    if (hi[i] == 0.0 && w[i] <= 0.0) continue;
+    const double dir = (w[i] <= 0.0) ? 1.0 : -1.0;
+    for (int k = 0; k < index; ++k) dxS[k] = -dir * AT(A, i, k);
+    otk_lltsolve(L, n, index, dxS);
+    const double delta_xi = dir;
+    while (1) {
+      ++steps;
+      for (int r = index; r < i; ++r) {
+        double t = 0.0;
+        for (int k = 0; k < index; ++k) t = t + AT(A, r, k) * dxS[k];
+        dwNS[r - index] = t + AT(A, i, r) * dir;
+      }
+      double delta_wi = 0.0;
+      for (int k = 0; k < index; ++k) delta_wi = delta_wi + AT(A, i, k) * dxS[k];
+      delta_wi = delta_wi + AT(A, i, i) * dir;
+      double best_alpha = -w[i] / delta_wi;
+      int best_index = i, index_i_into_set = 1;
+      const double index_i_limit = (dir > 0.0) ? hi[i] : lo[i];
+      {
+        const double alpha = (index_i_limit - x[i]) / delta_xi;
+        if (alpha > 0.0 && alpha < best_alpha) { best_alpha = alpha; best_index = i; index_i_into_set = 0; }
+      }
+      for (int j = 0; j < index; ++j) {
+        limit[j] = (dxS[j] > 0.0) ? hi[j] : lo[j];
+        const double alpha = (limit[j] - x[j]) / dxS[j];
+        if (alpha > 0.0 && alpha < best_alpha) { best_alpha = alpha; best_index = j; }
+      }
+      for (int j = index; j < i; ++j) {
+        const double alpha = -w[j] / dwNS[j - index];
+        if (alpha > 0.0 && alpha < best_alpha) { best_alpha = alpha; best_index = j; }
+      }
+      for (int k = 0; k < index; ++k) x[k] = x[k] + best_alpha * dxS[k];
+      x[i] = x[i] + best_alpha * delta_xi;
+      for (int r = index; r < i; ++r) w[r] = w[r] + best_alpha * dwNS[r - index];
+      w[i] = w[i] + best_alpha * delta_wi;
+      index_i_into_set = (best_index == i && index_i_into_set);
+      if (best_index < index) {
+        x[best_index] = limit[best_index];
+        if (otk_swap_cholesky_rows(A, n, best_index, index, L, work)) { ok = 0; break; }
+        otk_swap_rows_and_columns(A, n, index - 1, best_index, perm);
+        swapd(x, index - 1, best_index); swapd(lo, index - 1, best_index); swapd(hi, index - 1, best_index);
+        --index;
+        for (int k = 0; k < index; ++k) dxS[k] = -dir * AT(A, i, k);
+        otk_lltsolve(L, n, index, dxS);
+      } else if (best_index < i || index_i_into_set) {
+        w[index_i_into_set ? i : best_index] = 0.0;
+        otk_swap_rows_and_columns(A, n, index, best_index, perm);
+        swapd(x, index, best_index); swapd(w, index, best_index); swapd(lo, index, best_index); swapd(hi, index, best_index);
+        if (otk_add_cholesky_row(A, n, index + 1, L)) { ok = 0; break; }
+        if (best_index != i) {
+          double t = 0.0;
+          for (int k = 0; k < index; ++k) t = t + AT(A, index, k) * dxS[k];
+          const double value = (-dir * AT(A, i, index) - t) / (AT(L, index, index) * AT(L, index, index));
+          dxS[index] = value;
+          for (int k = 0; k < index; ++k) v[k] = AT(L, index, k);
+          otk_ltsolve(L, n, index, v);
+          for (int k = 0; k < index; ++k) dxS[k] = dxS[k] - value * v[k];
+        }
+        ++index;
+      } else {
+        x[i] = index_i_limit;
+      }
+      if (best_index == i) break;
+    }
+  }
+  for (int k = 0; k < n; ++k) { x_out[perm[k]] = x[k]; w_out[perm[k]] = w[k]; if (perm_out) perm_out[k] = perm[k]; }
+  if (pivots) *pivots = steps;
+  free(buf); free(perm);
+  return ok;
+}

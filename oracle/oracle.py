@@ -290,6 +290,51 @@ def mixed_constraints(A, b, Ceq, lo, hi, use_bounds=0):
     return bool(ok), x, w, piv.value
 
 
+# ---- toolkit/lcp.cc: incremental-factor box LCP (lcp_toolkit.c) --------------
+def tk_cholesky(A):
+    L = _f64(A).copy()
+    n = L.shape[0]
+    rc = lib().otk_cholesky(_p(L), C.c_int(n))
+    return rc == 0, L
+
+
+def tk_lsolve(L, m, b, transpose=False):
+    L, x = _f64(L), _f64(b).copy()
+    (lib().otk_ltsolve if transpose else lib().otk_lsolve)(_p(L), C.c_int(L.shape[0]), C.c_int(m), _p(x))
+    return x
+
+
+def tk_add_cholesky_row(A, m, L):
+    A, L = _f64(A), _f64(L).copy()
+    rc = lib().otk_add_cholesky_row(_p(A), C.c_int(A.shape[0]), C.c_int(m), _p(L))
+    return rc == 0, L
+
+
+def tk_swap_cholesky_rows(A, i, m, L):
+    A, L = _f64(A), _f64(L).copy()
+    n = A.shape[0]
+    work = np.zeros(2 * n)
+    rc = lib().otk_swap_cholesky_rows(_p(A), C.c_int(n), C.c_int(i), C.c_int(m), _p(L), _p(work))
+    return rc == 0, L
+
+
+def tk_swap_rows_and_columns(A, i, j, perm):
+    A = _f64(A).copy()
+    perm = np.ascontiguousarray(perm, dtype=np.int32).copy()
+    lib().otk_swap_rows_and_columns(_p(A), C.c_int(A.shape[0]), C.c_int(i), C.c_int(j), _p(perm))
+    return A, perm
+
+
+def tk_box_dantzig(A, b, lo, hi):
+    """SolveLCP_BoxDantzig: returns ok, x, w, A permuted in place (lower triangle), perm, pivots."""
+    A = _f64(A).copy()
+    b, lo, hi = _f64(b), _f64(lo), _f64(hi)
+    n = b.shape[0]
+    x = np.zeros(n); w = np.zeros(n); perm = np.zeros(n, np.int32); piv = C.c_int(0)
+    ok = lib().otk_box_dantzig(C.c_int(n), _p(A), _p(b), _p(lo), _p(hi), _p(x), _p(w), _p(perm), C.byref(piv))
+    return ok == 1, x, w, A, perm, piv.value
+
+
 # ---- collision ------------------------------------------------------------
 def collide_box_ground(c, R, side=(0.3, 0.3, 0.3)):
     c, R, side = _f64(c), _f64(R), _f64(side)

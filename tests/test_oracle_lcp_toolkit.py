@@ -1,0 +1,127 @@
+"""CPU: the oracle's restatement of toolkit/lcp.cc's incremental-factor box LCP (oracle/lcp_toolkit.c)
+held against the reference's OWN property tests, restated with their sizes and tolerances
+(toolkit/lcp.cc:799-1078: N = 7, 1000 random SPD problems; Cholesky / LSolve / AddCholeskyRow 1e-10,
+SwapCholeskyRows against a refactorisation 1e-9, Dantzig box-LCP conditions and |Ax - b - w| < 1e-6),
+plus agreement with the oracle's dense box Murty (lcp_dense.c), an independent route to the same
+unique solution.  The reference holds no golden vectors for this path ("parity unpinned")."""
+import numpy as np
+
+from oracle import oracle as orc
+
+N = 7
+
+
+def spd(rng, n, ridge=0.0):
+    A0 = rng.uniform(-1, 1, (n, n))
+    return A0 @ A0.T + ridge * np.eye(n)
+
+
+def lower(A):
+    return np.tril(A)          # only the lower triangle is handed over, as the reference's tests do
+
+
+def check_box_lcp(A, b, lo, hi, x, w):
+    for i in range(len(b)):
+        assert ((lo[i] <= x[i] <= hi[i]) and w[i] == 0) or (x[i] == lo[i] and w[i] >= 0) or (x[i] == hi[i] and w[i] <= 0), i
+    assert np.linalg.norm(A @ x - b - w) < 1e-6
+
+
+def test_cholesky_and_solves():      # toolkit/lcp.cc:1007-1035
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        A = spd(rng, N)
+        ok, L = orc.tk_cholesky(lower(A))
+        assert ok and np.linalg.norm(np.tril(L) - np.linalg.cholesky(A)) < 1e-10
+        for n in range(1, N):
+            b = rng.uniform(-1, 1, n)
+            x = orc.tk_lsolve(L, n, b)
+            assert np.linalg.norm(np.tril(L)[:n, :n] @ x - b) < 1e-10
+            y = orc.tk_lsolve(L, n, b, transpose=True)
+            assert np.linalg.norm(np.tril(L)[:n, :n].T @ y - b) < 1e-10
+
+
+def test_add_cholesky_row():         # toolkit/lcp.cc:1037-1049
+    rng = np.random.default_rng(2)
+    for n in range(1, N + 1):
+        A = spd(rng, N)
+        Lfull = np.linalg.cholesky(A)
+        L = Lfull.copy()
+        L[n - 1:, :] = 0.0
+        L[:, n - 1:] = 0.0
+        ok, L2 = orc.tk_add_cholesky_row(lower(A), n, L)
+        assert ok and np.linalg.norm(np.tril(L2)[:n, :n] - Lfull[:n, :n]) < 1e-10
+
+
+def test_swap_cholesky_rows_against_refactorisation():      # toolkit/lcp.cc:1051-1078
+    rng = np.random.default_rng(3)
+    for sz in range(N, N + 5):
+        for n in range(N):
+            A = spd(rng, sz)
+            L = np.linalg.cholesky(A)
+            ok, L2 = orc.tk_swap_cholesky_rows(lower(A), n, N, L)
+            assert ok
+            A2 = A.copy()
+            A2[:, [n, N - 1]] = A2[:, [N - 1, n]]
+            A2[[n, N - 1], :] = A2[[N - 1, n], :]
+            Lref = np.linalg.cholesky(A2)
+            assert np.linalg.norm(np.tril(L2)[:N - 1, :N - 1] - Lref[:N - 1, :N - 1]) < 1e-9, (sz, n)
+            if sz > N:
+                assert np.array_equal(L2[N:, :], L[N:, :])      # rows beyond the block are not touched
+
+
+def test_swap_rows_and_columns_touches_the_lower_triangle_only():      # toolkit/lcp.cc:171-195
+    rng = np.random.default_rng(4)
+    n = 9
+    A = spd(rng, n)
+    marked = np.tril(A) + np.triu(np.full((n, n), 777.0), 1)
+    for i, j in ((0, 8), (2, 5), (5, 2), (3, 4), (6, 6)):
+        P, perm = orc.tk_swap_rows_and_columns(marked, i, j, np.arange(n))
+        assert np.array_equal(np.triu(P, 1), np.triu(marked, 1))
+        want = A[np.ix_(perm, perm)]
+        assert np.array_equal(np.tril(P), np.tril(want))
+
+
+def test_box_dantzig_reference_property_test():      # toolkit/lcp.cc:947-1003
+    rng = np.random.default_rng(5)
+    for it in range(1000):
+        A = spd(rng, N, 0.001)
+        b = rng.uniform(-1, 1, N)
+        lo_range, hi_range = 10.0, 10.0
+        v = it % 6
+        if v == 1: lo_range, hi_range = 100.0, 100.0
+        elif v == 2: lo_range = hi_range = 1e99
+        elif v == 3: lo_range, hi_range = 1.0, 1.0
+        elif v == 4: lo_range = 0.0
+        elif v == 5: hi_range = 0.0
+        lo = -rng.uniform(0, 1, N) * lo_range
+        hi = rng.uniform(0, 1, N) * hi_range
+        lo = lo + 0.0; hi = hi + 0.0          # no negative zeros
+        for i in range(N):
+            r = int(rng.integers(0, 100))
+            if r == 0 and hi[i] != 0: lo[i] = 0.0
+            elif r == 1 and lo[i] != 0: hi[i] = 0.0
+        keep = ~((lo == 0) & (hi == 0))      # the algorithm requires lo < hi (toolkit/lcp.cc:448-450)
+        if not keep.all():
+            hi[~keep] = 1.0
+        ok, x, w, Ap, perm, piv = orc.tk_box_dantzig(lower(A), b, lo, hi)
+        assert ok
+        check_box_lcp(A, b, lo, hi, x, w)
+        # A is permuted in place (toolkit/lcp.h:170-171): lower triangle of P A P'
+        assert np.allclose(np.tril(Ap), np.tril(A[np.ix_(perm, perm)]), rtol=0, atol=0)
+        assert sorted(perm.tolist()) == list(range(N))
+
+
+def test_box_dantzig_agrees_with_the_dense_box_murty():
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 5, 12, 30, 64):
+        for _ in range(10):
+            A = spd(rng, n, 0.05)
+            b = rng.uniform(-2, 2, n)
+            lo = -rng.uniform(0.05, 2, n); hi = rng.uniform(0.05, 2, n)
+            hi[rng.uniform(size=n) < 0.3] = np.inf
+            lo[rng.uniform(size=n) < 0.2] = 0.0
+            ok, x, w, Ap, perm, piv = orc.tk_box_dantzig(lower(A), b, lo, hi)
+            assert ok
+            check_box_lcp(A, b, lo, hi, x, w)
+            ok2, x2, w2, _ = orc.mixed_constraints(A, b, np.zeros(n, np.uint8), lo, hi, 1)     # true box Murty
+            assert ok2 and np.abs(x - x2).max() < 1e-8 and np.abs(w - w2).max() < 1e-8
