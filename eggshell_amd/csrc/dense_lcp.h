@@ -30,4 +30,12 @@ bool dense_mixed_constraints_device(hipStream_t stream, int N, const double *dA,
 // a JacobiSVD (utils.cc:256-261).  *spd = false (and +inf) if the factorisation breaks down.
 double dense_condition_estimate(hipStream_t stream, int N, const double *dA, bool *spd);
 
+// lcp::SolveLCP_BoxDantzig with the incremental Cholesky factor of toolkit/lcp.cc (dantzig.hip): one wavefront,
+// everything in LDS, n <= kDantzigMaxRows.  A (host, row-major n x n; only the lower triangle is read) is permuted
+// in place as the reference leaves it (lower triangle written back); perm[k] = original index of final row k (may
+// be NULL).  Needs lo <= 0 <= hi, lo < hi (toolkit/lcp.cc:448-450).  max_steps > 0: give up after that many steps.
+constexpr int kDantzigMaxRows = 96;
+bool box_lcp_dantzig(hipStream_t stream, int n, double *A, const double *b, const double *lo, const double *hi, double *x,
+                     double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg);
+
 }  // namespace egs

@@ -215,6 +215,20 @@ static void round2() {
     ok = lcp::SolveLCP(st, A4, b, lo, hi, &x, &w);
     std::printf("lcp_nobox_ok %d\n", ok ? 1 : 0);
     print_vec("lcp_nobox_x", x); print_vec("lcp_nobox_w", w);
+    {  // algorithm = COTTLE_DANTZIG without the Schur complement: SolveLCP_BoxDantzig itself (toolkit/lcp.cc:776-779)
+      lcp::Settings dz;
+      dz.algorithm = lcp::COTTLE_DANTZIG;
+      dz.schur_complement = false;
+      VectorXd lod(n), hid(n);
+      for (int i = 0; i < n; ++i) { lod(i) = (i % 4 == 1) ? 0.0 : -0.25; hid(i) = (i % 5 == 2) ? inf : 0.5; }
+      MatrixXd A6 = A;
+      ok = lcp::SolveLCP(dz, A6, b, lod, hid, &x, &w);
+      std::printf("lcp_dantzig_ok %d %d\n", ok ? 1 : 0, lcp::LastSolvePivots());
+      print_vec("lcp_dantzig_x", x); print_vec("lcp_dantzig_w", w);
+      VectorXd A6v(n * n);
+      for (int i = 0; i < n * n; ++i) A6v(i) = A6.data()[i];
+      print_vec("lcp_dantzig_A", A6v);             // lower triangle permuted in place by the pivoting order
+    }
     int refused = 0;
     st.schur_complement = true;                    // Schur complement without box_lcp: the reference Panics
     try { MatrixXd A5 = A; (void)lcp::SolveLCP(st, A5, b, lo, hi, &x, &w); } catch (const egs::Error &e) { refused = e.status; }

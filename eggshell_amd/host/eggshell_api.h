@@ -191,10 +191,14 @@ bool MixedConstraintsSolver(const MatrixXd &A, const VectorXd &b, const ArrayXb 
 //     FINITE hi is classed unbounded) is reproduced when reference_quirks is set;
 //   * max_iterations and max_time: the solve gives up and returns false (toolkit/lcp.h:161-167);
 //   * box_lcp = false: lo = 0, hi = +inf whatever the vectors hold (toolkit/lcp.h:152-154).
-// What differs, by design: `algorithm` picks no different code -- block
-// principal pivoting with a single-index safeguard finds the same unique solution for both
-// -- there is no incremental Cholesky (LinearReducer), so with schur_complement = false A is
-// left untouched instead of carrying the pivoting order of SolveLCP_BoxMurty.
+//   * algorithm = COTTLE_DANTZIG with schur_complement = false (toolkit/lcp.cc:776-779) runs
+//     SolveLCP_BoxDantzig itself on the device (egs_box_lcp_dantzig: Cottle-Dantzig pivoting with the
+//     incremental Cholesky factor of AddCholeskyRow / SwapCholeskyRows, toolkit/lcp.cc:91-157) for up to
+//     96 rows, and A's lower triangle is permuted in place by its pivoting order, as in the reference.
+// What differs, by design: algorithm = MURTY, the Schur-reduced problem and
+// Dantzig problems beyond 96 rows all go through block principal pivoting with a single-index safeguard
+// (fresh blocked factorisations on the matrix cores; same unique solution), so there A is left in
+// BoxSchur's order or untouched instead of carrying LinearReducer's pivoting order.
 namespace lcp {
 enum Algorithm { MURTY, COTTLE_DANTZIG };
 struct Settings {

@@ -335,6 +335,20 @@ egs_status egs_world_get_contacts(egs_world *w, int32_t max_contacts, int32_t *m
 egs_status egs_world_get_lambda(egs_world *w, int32_t max_rows, int32_t *rows_out, double *lambda);
 egs_status egs_world_info(egs_world *w, int32_t *n_constraints, int32_t *n_contacts, int32_t *replans);
 
+/* Replaces lcp::SolveLCP_BoxDantzig (toolkit/lcp.cc:444-619; reached from lcp::SolveLCP with
+ * Settings.algorithm = COTTLE_DANTZIG, box_lcp = true, schur_complement = false, toolkit/lcp.cc:776-779):
+ * Cottle-Dantzig principal pivoting on A x = b + w with lo <= x <= hi, the Cholesky factor of the active
+ * set kept up to date row by row (AddCholeskyRow / SwapCholeskyRows, toolkit/lcp.cc:91-157; O(n^2) per
+ * pivot).  A [n][n] row-major: only the lower triangle is read, and it is PERMUTED IN PLACE exactly as the
+ * reference leaves it (toolkit/lcp.h:170-171); perm[k] = original index of the final row k (may be NULL).
+ * Requires lo <= 0 <= hi and lo < hi (toolkit/lcp.cc:448-450: EGS_ERR_INVALID otherwise) and
+ * 1 <= n <= 96 (one wavefront, both matrices in LDS; larger problems: egs_mixed_constraints_solve with
+ * use_bounds = 3 reaches the same solution with blocked factorisations).  max_steps > 0 gives up after that
+ * many pivot steps (*ok = 0, EGS_ERR_LCP_FAILED), as does a non-positive pivot (A not positive definite).  */
+egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo,
+                               const double *hi, int32_t max_steps, double *x, double *w, int32_t *perm,
+                               int32_t *ok, int32_t *pivots);
+
 /* ---- diagnostics (host only, needs no GPU) -------------------------------
  * The schedule the solver derives from the constraint graph: islands, the
  * workgroup tile each constraint lands in (-1 = cross-workgroup path) and the

@@ -192,6 +192,20 @@ def test_solvelcp_contract(out):
     assert int(out["lcp_nobox_ok"][0]) == 1
     x, w = out["lcp_nobox_x"], out["lcp_nobox_w"]
     assert np.linalg.norm(A @ x - b - w) < 1e-9 and (x >= 0).all() and (w >= -1e-9).all() and abs(x @ w) < 1e-8
+    # algorithm = COTTLE_DANTZIG, schur_complement = false: SolveLCP_BoxDantzig with the incremental factor; the
+    # oracle's restatement (oracle/lcp_toolkit.c) takes the same steps and leaves the same permuted lower triangle
+    lod = np.array([0.0 if i % 4 == 1 else -0.25 for i in range(n)]); hid = np.array([np.inf if i % 5 == 2 else 0.5 for i in range(n)])
+    okd, pivd = out["lcp_dantzig_ok"].astype(int)
+    oko, xo, wo, Ao, permo, pivo = orc.tk_box_dantzig(A, b, lod, hid)
+    assert okd == 1 and oko and pivd == pivo
+    assert np.abs(out["lcp_dantzig_x"] - xo).max() < 1e-12 and np.abs(out["lcp_dantzig_w"] - wo).max() < 1e-12
+    Ad = out["lcp_dantzig_A"].reshape(n, n)
+    # (the demo builds A with its own summation order: equal to the numpy A to rounding, hence tolerances here;
+    #  tests/test_gpu_dantzig.py compares bit for bit through the C ABI)
+    assert np.abs(np.tril(Ad) - np.tril(Ao)).max() < 1e-12 and np.abs(np.tril(Ad) - np.tril(A[np.ix_(permo, permo)])).max() < 1e-12
+    assert np.abs(np.triu(Ad, 1) - np.triu(A, 1)).max() < 1e-12     # the upper triangle is neither read nor written
+    xd, wd = out["lcp_dantzig_x"], out["lcp_dantzig_w"]
+    assert np.linalg.norm(A @ xd - b - wd) < 1e-9 and (xd >= lod).all() and (xd <= hid).all()
     assert int(out["lcp_refused"][0]) == capi.ERR_INVALID          # Schur complement without box_lcp
     ok, piv = out["lcp_big_ok"].astype(int)
     assert ok == 1 and piv > 1

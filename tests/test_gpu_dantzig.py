@@ -1,0 +1,87 @@
+"""GPU (-m gpu): lcp::SolveLCP_BoxDantzig with the incremental Cholesky factor (toolkit/lcp.cc:91-157,
+444-619) on the device, through the C ABI (egs_box_lcp_dantzig), against the oracle's restatement
+(oracle/lcp_toolkit.c, pinned by the reference's own property tests in tests/test_oracle_lcp_toolkit.py):
+the reference's Dantzig property test restated (N = 7, 6 bound variants, box-LCP conditions, |Ax - b - w| <
+1e-6), the same pivot sequence and the same in-place permutation of A as the sequential algorithm, sizes up
+to the 96-row limit, and the documented refusals."""
+import numpy as np
+import pytest
+
+from eggshell_amd import capi
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def spd(rng, n, ridge):
+    A0 = rng.uniform(-1, 1, (n, n))
+    return A0 @ A0.T + ridge * np.eye(n)
+
+
+def check_box_lcp(A, b, lo, hi, x, w):
+    for i in range(len(b)):
+        assert ((lo[i] <= x[i] <= hi[i]) and w[i] == 0) or (x[i] == lo[i] and w[i] >= 0) or (x[i] == hi[i] and w[i] <= 0), i
+    assert np.linalg.norm(A @ x - b - w) < 1e-6
+
+
+def test_reference_property_test_n7(ctx):      # toolkit/lcp.cc:947-1003
+    rng = np.random.default_rng(5)
+    N = 7
+    for it in range(120):
+        A = spd(rng, N, 0.001)
+        b = rng.uniform(-1, 1, N)
+        lo_range, hi_range = [(10, 10), (100, 100), (1e99, 1e99), (1, 1), (0, 10), (10, 0)][it % 6]
+        lo = -rng.uniform(0, 1, N) * lo_range + 0.0
+        hi = rng.uniform(0, 1, N) * hi_range + 0.0
+        dead = (lo == 0) & (hi == 0)
+        hi[dead] = 1.0
+        ok, x, w, Ap, perm, piv = ctx.box_lcp_dantzig(np.tril(A), b, lo, hi)
+        assert ok
+        check_box_lcp(A, b, lo, hi, x, w)
+        oko, xo, wo, Ao, permo, pivo = orc.tk_box_dantzig(np.tril(A), b, lo, hi)
+        # the same steps as the sequential algorithm: pivot count, permutation and the matrix left behind
+        assert piv == pivo and np.array_equal(perm, permo)
+        assert np.array_equal(np.tril(Ap), np.tril(Ao))
+        assert np.array_equal(np.tril(Ap), np.tril(A[np.ix_(perm, perm)]))
+        assert np.abs(x - xo).max() < 1e-12 and np.abs(w - wo).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 2, 13, 40, 64, 65, 96])
+def test_sizes_up_to_the_limit(ctx, n):
+    rng = np.random.default_rng(100 + n)
+    for trial in range(3):
+        A = spd(rng, n, 0.05)
+        b = rng.uniform(-2, 2, n)
+        lo = -rng.uniform(0.05, 2, n); hi = rng.uniform(0.05, 2, n)
+        hi[rng.uniform(size=n) < 0.3] = np.inf
+        lo[rng.uniform(size=n) < 0.2] = 0.0
+        upper_marked = np.tril(A) + np.triu(np.full((n, n), 555.0), 1)          # the upper triangle is never read ...
+        ok, x, w, Ap, perm, piv = ctx.box_lcp_dantzig(upper_marked, b, lo, hi)
+        assert ok
+        assert np.array_equal(np.triu(Ap, 1), np.triu(upper_marked, 1))          # ... nor written
+        check_box_lcp(A, b, lo, hi, x, w)
+        oko, xo, wo, Ao, permo, pivo = orc.tk_box_dantzig(np.tril(A), b, lo, hi)
+        assert oko and piv == pivo and np.array_equal(perm, permo)
+        assert np.abs(x - xo).max() < 1e-10 and np.abs(w - wo).max() < 1e-10
+        ok2, x2, w2, _ = orc.mixed_constraints(A, b, np.zeros(n, np.uint8), lo, hi, 1)   # independent route: dense box Murty
+        assert ok2 and np.abs(x - x2).max() < 1e-8
+
+
+def test_refusals_and_limits(ctx):
+    rng = np.random.default_rng(9)
+    n = 10
+    A = spd(rng, n, 0.1); b = rng.uniform(-1, 1, n)
+    lo = -np.ones(n); hi = np.ones(n)
+    with pytest.raises(capi.EgsError) as e:      # lo must be <= 0 (toolkit/lcp.cc:448-450)
+        ctx.box_lcp_dantzig(A, b, lo + 2.0, hi + 2.0)
+    assert e.value.status == capi.ERR_INVALID
+    with pytest.raises(capi.EgsError) as e:      # beyond the single-wavefront limit
+        ctx.box_lcp_dantzig(spd(rng, 97, 0.1), np.zeros(97), -np.ones(97), np.ones(97))
+    assert e.value.status == capi.ERR_INVALID
+    ok, x, w, Ap, perm, piv = ctx.box_lcp_dantzig(A, b, lo, hi, max_steps=1)      # max_iterations-style give-up
+    full = ctx.box_lcp_dantzig(A, b, lo, hi)
+    assert full[0] and (ok or piv > 1) and (not ok or full[5] <= 1)
+    Abad = A.copy(); Abad[3, 3] = -5.0                                            # not positive definite
+    ok, *_ = ctx.box_lcp_dantzig(Abad, b, lo, hi)
+    oko = orc.tk_box_dantzig(Abad, b, lo, hi)[0]
+    assert ok == oko
