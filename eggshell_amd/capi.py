@@ -33,7 +33,7 @@ EXPORTS = [
     "egs_world_set_joints", "egs_world_step", "egs_world_get_bodies", "egs_world_get_contacts",
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
-    "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig",
+    "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig", "egs_box_lcp_murty",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -194,14 +194,18 @@ class Context:
         return bool(ok.value), x, w, piv.value
 
 
-    def box_lcp_dantzig(self, A, b, lo, hi, max_steps=0):
+    def box_lcp_murty(self, A, b, lo, hi, max_iterations=0):
+        """lcp::SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442), n <= 96."""
+        return self.box_lcp_dantzig(A, b, lo, hi, max_iterations, _entry="egs_box_lcp_murty")
+
+    def box_lcp_dantzig(self, A, b, lo, hi, max_steps=0, _entry="egs_box_lcp_dantzig"):
         """lcp::SolveLCP_BoxDantzig with the incremental factor (toolkit/lcp.cc:444-619), n <= 96.
         Returns ok, x, w, A permuted in place (lower triangle), perm, pivot steps."""
         A = _f64(A).copy()
         b, lo, hi = map(_f64, (b, lo, hi))
         n = b.shape[0]
         x = np.zeros(n); w = np.zeros(n); perm = np.zeros(n, np.int32); ok = C.c_int32(0); piv = C.c_int32(0)
-        st = load().egs_box_lcp_dantzig(self.h, C.c_int32(n), _p(A), _p(b), _p(lo), _p(hi), C.c_int32(max_steps),
+        st = getattr(load(), _entry)(self.h, C.c_int32(n), _p(A), _p(b), _p(lo), _p(hi), C.c_int32(max_steps),
                                         _p(x), _p(w), _p(perm), C.byref(ok), C.byref(piv))
         if st not in (OK, ERR_LCP_FAILED):
             self.check(st)

@@ -1534,22 +1534,32 @@ egs_status egs_mixed_constraints_solve_limits(egs_context *ctx, int32_t N, const
   });
 }
 
-egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo, const double *hi,
-                               int32_t max_steps, double *x, double *w, int32_t *perm, int32_t *ok, int32_t *pivots) {
+static egs_status box_lcp_incremental_entry(egs_context *ctx, int algorithm, int32_t n, double *A, const double *b, const double *lo,
+                                     const double *hi, int32_t max_steps, double *x, double *w, int32_t *perm, int32_t *ok,
+                                     int32_t *pivots) {
   if (!ctx) return EGS_ERR_INVALID;
   if (ok) *ok = 0;
-  if (n < 1 || n > kDantzigMaxRows) return fail(ctx, EGS_ERR_INVALID, "egs_box_lcp_dantzig: 1 <= n <= 96");
+  if (n < 1 || n > kDantzigMaxRows) return fail(ctx, EGS_ERR_INVALID, "incremental box LCP: 1 <= n <= 96");
   if (!A || !b || !lo || !hi || !x || !w) return fail(ctx, EGS_ERR_INVALID, "NULL array");
   return guarded(ctx, [&]() -> egs_status {
     HIPCHK(hipSetDevice(ctx->device));
     int piv = 0;
     std::string msg;
-    const bool good = box_lcp_dantzig(ctx->stream, n, A, b, lo, hi, x, w, perm, max_steps, &piv, &msg);
+    const bool good = box_lcp_incremental(ctx->stream, algorithm, n, A, b, lo, hi, x, w, perm, max_steps, &piv, &msg);
     if (ok) *ok = good ? 1 : 0;
     if (pivots) *pivots = piv;
-    if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "BoxDantzig did not reach a solution" : msg);
+    if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "the box LCP solver did not reach a solution" : msg);
     return EGS_OK;
   });
+}
+
+egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo, const double *hi,
+                               int32_t max_steps, double *x, double *w, int32_t *perm, int32_t *ok, int32_t *pivots) {
+  return box_lcp_incremental_entry(ctx, 1, n, A, b, lo, hi, max_steps, x, w, perm, ok, pivots);
+}
+egs_status egs_box_lcp_murty(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo, const double *hi,
+                             int32_t max_iterations, double *x, double *w, int32_t *perm, int32_t *ok, int32_t *iterations) {
+  return box_lcp_incremental_entry(ctx, 0, n, A, b, lo, hi, max_iterations, x, w, perm, ok, iterations);
 }
 
 egs_status egs_update_contacts_joints(egs_context *ctx, int32_t n, const double *pos, const double *R,

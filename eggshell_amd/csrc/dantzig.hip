@@ -285,6 +285,121 @@ __global__ void __launch_bounds__(64) box_dantzig_kernel(int n, double *gA, cons
   if (lane == 0) { res->ok = ok ? 1 : 0; res->pivots = steps; }
 }
 
+// in-place Cholesky of the lower triangle, column by column, a lane per row below the pivot (toolkit/lcp.cc:46-48)
+__device__ bool cholesky(double *L, int n, int lane) {
+  for (int j = 0; j < n; ++j) {
+    double d = AT(L, j, j);
+    for (int k = 0; k < j; ++k) d = d - AT(L, j, k) * AT(L, j, k);
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    wsync();
+    if (lane == 0) AT(L, j, j) = d;
+    for (int i = j + 1 + lane; i < n; i += 64) {
+      double s = AT(L, i, j);
+      for (int k = 0; k < j; ++k) s = s - AT(L, i, k) * AT(L, j, k);
+      AT(L, i, j) = s / d;
+    }
+    wsync();
+  }
+  return true;
+}
+
+// SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442); SolveLCP_Murty (:333-378) is the same loop
+// with lo = 0, hi = +inf.  gA in/out (lower triangle), gx / gw / gperm out.
+__global__ void __launch_bounds__(64) box_murty_kernel(int n, double *gA, const double *gb, const double *glo, const double *ghi,
+                                                       double *gx, double *gw, int32_t *gperm, DantzigResult *res,
+                                                       int max_iterations) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *A = reinterpret_cast<double *>(smem);
+  double *L = A + (size_t)n * n;
+  double *x = L + (size_t)n * n, *w = x + n, *lo = w + n, *hi = lo + n, *b = hi + n, *xs = b + n, *c = xs + n, *c2 = c + n,
+         *t = c2 + n, *wq = t + n, *temp = wq + n;
+  int *perm = reinterpret_cast<int *>(temp + n), *iperm = perm + n;
+  const int lane = threadIdx.x;
+  for (int k = lane; k < n * n; k += 64) {
+    const int r = k / n, q = k - r * n;
+    A[k] = gA[k];
+    L[k] = (q <= r) ? gA[k] : 0.0;
+  }
+  for (int k = lane; k < n; k += 64) { x[k] = 0.0; w[k] = 0.0; lo[k] = glo[k]; hi[k] = ghi[k]; b[k] = gb[k]; xs[k] = gb[k]; c[k] = 0.0; perm[k] = k; iperm[k] = k; }
+  wsync();
+  // LinearReducer::LinearReducer (:213-224): factor all of A, xs = A^-1 b
+  bool ok = cholesky(L, n, lane);
+  if (ok) lltsolve(L, n, n, xs, lane);
+  int index = n, it = 0;
+  bool solved = false;
+  for (; ok && it < max_iterations; ++it) {
+    // SubSolve (:245-296)
+    wsync();
+    if (index == 0) {
+      for (int i = lane; i < n; i += 64) x[i] = c[i];
+    } else if (index >= n) {
+      for (int i = lane; i < n; i += 64) x[perm[i]] = xs[i];
+    } else {
+      for (int i = lane; i < n; i += 64) c2[i] = c[perm[i]];
+      wsync();
+      for (int k = lane; k < index; k += 64) {
+        double s = 0.0;
+        for (int r = index; r < n; ++r) s = s + AT(A, r, k) * (c2[r] - xs[r]);
+        t[k] = s;
+      }
+      wsync();
+      lltsolve(L, n, index, t, lane);
+      for (int i = lane; i < n; i += 64) x[perm[i]] = (i < index) ? xs[i] - t[i] : c[perm[i]];
+    }
+    wsync();
+    // MultiplyA (:298-322) on the rows outside the set; w = A x - b there, 0 inside (:396-404).  c2 = x permuted
+    for (int i = lane; i < n; i += 64) c2[i] = x[perm[i]];
+    wsync();
+    for (int r = lane; r < n; r += 64) {
+      if (r < index) { w[perm[r]] = 0.0; continue; }
+      double s = 0.0;
+      for (int k = 0; k < index; ++k) s = s + AT(A, r, k) * c2[k];
+      double u = 0.0;
+      for (int k = index; k < n; ++k) u = u + ((k <= r) ? AT(A, r, k) : AT(A, k, r)) * c2[k];
+      w[perm[r]] = (s + u) - b[perm[r]];
+    }
+    wsync();
+    // first violated index in the caller's order (:408-431), found by every lane
+    int who = -1, dirn = 0;      // dirn: -1 leaves the set clamped at lo, -2 at hi, +1 enters the set
+    for (int i = 0; i < n; ++i) {
+      if (iperm[i] < index) {
+        if (x[i] < lo[i]) { who = i; dirn = -1; break; }
+        if (x[i] > hi[i]) { who = i; dirn = -2; break; }
+      } else {
+        if ((c[i] == lo[i] && w[i] < 0.0) || (c[i] == hi[i] && w[i] > 0.0)) { who = i; dirn = 1; break; }
+      }
+    }
+    if (who < 0) { solved = true; break; }
+    const int p = iperm[who];
+    wsync();
+    if (dirn < 0) {       // RemoveIndex (:236-243)
+      if (lane == 0) c[who] = (dirn == -1) ? lo[who] : hi[who];
+      if (!swap_cholesky_rows(A, n, p, index, L, wq, temp, lane)) { ok = false; break; }
+      --index;
+    }
+    if (index != p) {
+      const int a = perm[index], bq = perm[p];
+      swap_rows_and_columns(A, n, index, p, perm, lane);
+      if (lane == 0) { iperm[a] = p; iperm[bq] = index; const double tt = xs[index]; xs[index] = xs[p]; xs[p] = tt; }
+      wsync();
+    }
+    if (dirn > 0) {       // AddIndex (:226-234)
+      ++index;
+      if (!add_cholesky_row(A, n, index, L, lane)) { ok = false; break; }
+      if (lane == 0) c[who] = 0.0;
+    }
+    wsync();
+  }
+  wsync();
+  for (int k = lane; k < n; k += 64) { gx[k] = x[k]; gw[k] = w[k]; gperm[k] = perm[k]; }
+  for (int k = lane; k < n * n; k += 64) {
+    const int r = k / n, q = k - r * n;
+    if (q <= r) gA[k] = A[k];
+  }
+  if (lane == 0) { res->ok = (ok && solved) ? 1 : 0; res->pivots = it; }
+}
+
 #undef AT
 
 struct HipErr : std::runtime_error {
@@ -297,12 +412,14 @@ void chk(hipError_t e, const char *what) {
 
 }  // namespace
 
-bool box_lcp_dantzig(hipStream_t stream, int n, double *A, const double *b, const double *lo, const double *hi, double *x,
-                     double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg) {
-  if (n <= 0 || n > kDantzigMaxRows) throw std::invalid_argument("box_lcp_dantzig: 1 <= n <= 96");
+bool box_lcp_incremental(hipStream_t stream, int algorithm, int n, double *A, const double *b, const double *lo, const double *hi,
+                         double *x, double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg) {
+  if (n <= 0 || n > kDantzigMaxRows) throw std::invalid_argument("box_lcp_incremental: 1 <= n <= 96");
+  if (algorithm != 0 && algorithm != 1) throw std::invalid_argument("box_lcp_incremental: algorithm 0 (Murty) or 1 (Cottle-Dantzig)");
   for (int i = 0; i < n; ++i) {
-    // the algorithm's own preconditions (toolkit/lcp.cc:448-450)
-    if (!(lo[i] <= 0.0) || !(hi[i] >= 0.0) || !(lo[i] < hi[i])) throw std::invalid_argument("box_lcp_dantzig: needs lo <= 0 <= hi, lo < hi");
+    // lo <= 0 <= hi (toolkit/lcp.h:134); Dantzig also needs lo < hi (toolkit/lcp.cc:448-450)
+    if (!(lo[i] <= 0.0) || !(hi[i] >= 0.0) || (algorithm == 1 && !(lo[i] < hi[i])))
+      throw std::invalid_argument("box_lcp_incremental: needs lo <= 0 <= hi (and lo < hi for Cottle-Dantzig)");
   }
   const size_t nn = (size_t)n * n;
   double *dA = nullptr, *dv = nullptr;
@@ -319,10 +436,15 @@ bool box_lcp_dantzig(hipStream_t stream, int n, double *A, const double *b, cons
     HIPCHK(hipMemcpyAsync(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(dlo, lo, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(dhi, hi, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
-    const size_t lds = (2 * nn + 11 * (size_t)n) * sizeof(double) + (size_t)n * sizeof(int);
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(box_dantzig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(box_dantzig_kernel, dim3(1), dim3(64), lds, stream, n, dA, db, dlo, dhi, dx, dw, dperm, dres,
-                       max_steps > 0 ? max_steps : 0x7fffffff);
+    const size_t lds = (2 * nn + 11 * (size_t)n) * sizeof(double) + 2 * (size_t)n * sizeof(int);
+    const int limit = max_steps > 0 ? max_steps : 0x7fffffff;
+    if (algorithm == 1) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(box_dantzig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(box_dantzig_kernel, dim3(1), dim3(64), lds, stream, n, dA, db, dlo, dhi, dx, dw, dperm, dres, limit);
+    } else {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(box_murty_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(box_murty_kernel, dim3(1), dim3(64), lds, stream, n, dA, db, dlo, dhi, dx, dw, dperm, dres, limit);
+    }
     HIPCHK(hipGetLastError());
     DantzigResult r{};
     std::vector<int32_t> hperm(n);
@@ -335,7 +457,7 @@ bool box_lcp_dantzig(hipStream_t stream, int n, double *A, const double *b, cons
     if (perm) for (int i = 0; i < n; ++i) perm[i] = hperm[i];
     if (pivots) *pivots = r.pivots;
     good = r.ok != 0;
-    if (!good && msg) *msg = (max_steps > 0 && r.pivots > max_steps) ? "BoxDantzig: step limit reached" : "BoxDantzig: a factor update met a non-positive pivot (A not positive definite?)";
+    if (!good && msg) *msg = (max_steps > 0 && r.pivots >= max_steps) ? "incremental box LCP: iteration limit reached" : "incremental box LCP: a factor update met a non-positive pivot (A not positive definite?)";
   } catch (...) {
     (void)hipFree(dA); (void)hipFree(dv); (void)hipFree(dperm); (void)hipFree(dres);
     throw;

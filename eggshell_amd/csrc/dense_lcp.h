@@ -35,7 +35,9 @@ double dense_condition_estimate(hipStream_t stream, int N, const double *dA, boo
 // in place as the reference leaves it (lower triangle written back); perm[k] = original index of final row k (may
 // be NULL).  Needs lo <= 0 <= hi, lo < hi (toolkit/lcp.cc:448-450).  max_steps > 0: give up after that many steps.
 constexpr int kDantzigMaxRows = 96;
-bool box_lcp_dantzig(hipStream_t stream, int n, double *A, const double *b, const double *lo, const double *hi, double *x,
-                     double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg);
+// algorithm 1 = SolveLCP_BoxDantzig, 0 = SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442; with
+// lo = 0, hi = +inf it is SolveLCP_Murty, :333-378); max_steps = Settings::max_iterations.
+bool box_lcp_incremental(hipStream_t stream, int algorithm, int n, double *A, const double *b, const double *lo, const double *hi,
+                         double *x, double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg);
 
 }  // namespace egs

@@ -167,12 +167,16 @@ bool lcp::SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, con
   int32_t ok = 0, pivots = 0;
   const int max_piv = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
   const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
-  if (settings.algorithm == COTTLE_DANTZIG && N <= 96) {
-    // SolveLCP_BoxDantzig (toolkit/lcp.cc:444-619) with its incremental factor, on the device; A's lower
-    // triangle carries the pivoting order afterwards, as in the reference.  Its preconditions
-    // (lo <= 0 <= hi, lo < hi, :448-450) come back as EGS_ERR_INVALID.
-    egs_status st = egs_box_lcp_dantzig(egs::DefaultContext(), N, A.data(), b.data(), l.data(), h.data(), 0, x->data(), w->data(),
-                                        nullptr, &ok, &pivots);
+  if (N <= 96) {
+    // Without the Schur complement the reference runs SolveLCP_BoxDantzig (toolkit/lcp.cc:444-619) or
+    // SolveLCP_BoxMurty / SolveLCP_Murty on a LinearReducer (:213-442): both on the device with their
+    // incremental Cholesky factor; A's lower triangle carries the pivoting order afterwards, as in the
+    // reference.  Their preconditions (lo <= 0 <= hi; lo < hi for Dantzig, :448-450) come back as
+    // EGS_ERR_INVALID, the iteration limit as false.
+    const int lim = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
+    egs_status st = settings.algorithm == COTTLE_DANTZIG
+        ? egs_box_lcp_dantzig(egs::DefaultContext(), N, A.data(), b.data(), l.data(), h.data(), 0, x->data(), w->data(), nullptr, &ok, &pivots)
+        : egs_box_lcp_murty(egs::DefaultContext(), N, A.data(), b.data(), l.data(), h.data(), lim, x->data(), w->data(), nullptr, &ok, &pivots);
     g_last_lcp_pivots = pivots;
     if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
     return ok != 0;

@@ -349,6 +349,16 @@ egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const dou
                                const double *hi, int32_t max_steps, double *x, double *w, int32_t *perm,
                                int32_t *ok, int32_t *pivots);
 
+/* Replaces lcp::SolveLCP_BoxMurty (toolkit/lcp.cc:380-442; with lo = 0, hi = +inf / DBL_MAX it is
+ * SolveLCP_Murty, :333-378) on its LinearReducer (:213-328): principal pivoting that moves the first
+ * violated index (in the caller's order) in or out of the index set and keeps the set's Cholesky factor
+ * up to date row by row.  Same arguments, limits (n <= 96, lo <= 0 <= hi) and in-place permutation of A's
+ * lower triangle as egs_box_lcp_dantzig; max_iterations > 0 = Settings::max_iterations (the call then
+ * reports *ok = 0, EGS_ERR_LCP_FAILED, as the reference returns false, toolkit/lcp.cc:438-441).       */
+egs_status egs_box_lcp_murty(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo,
+                             const double *hi, int32_t max_iterations, double *x, double *w, int32_t *perm,
+                             int32_t *ok, int32_t *iterations);
+
 /* ---- diagnostics (host only, needs no GPU) -------------------------------
  * The schedule the solver derives from the constraint graph: islands, the
  * workgroup tile each constraint lands in (-1 = cross-workgroup path) and the

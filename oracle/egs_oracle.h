@@ -174,6 +174,8 @@ int otk_swap_cholesky_rows(const double *A, int n, int i, int m, double *L, doub
 void otk_swap_rows_and_columns(double *A, int n, int i, int j, int *perm);
 int otk_box_dantzig(int n, double *A, const double *b, const double *lo, const double *hi,
                     double *x, double *w, int *perm_out, int *pivots);
+int otk_box_murty(int n, double *A, const double *b, const double *lo, const double *hi, int max_iterations,
+                  double *x, double *w, int *perm_out, int *iters);
 
 int orc_collide_box_ground(const double c[3], const double R[9],
                            const double side[3], double *contacts);

@@ -254,3 +254,95 @@ int otk_box_dantzig(int n, double *A, const double *b, const double *lo_arg, con
   free(buf); free(perm);
   return ok;
 }
+
+/* SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442): principal pivoting that keeps the
+ * Cholesky factor of the index set up to date by AddCholeskyRow / SwapCholeskyRows.  SolveLCP_Murty (:333-378)
+ * is the same loop with lo = 0, hi = +inf (its extra tests `w > 0` inside and `x > 0` outside the set can never
+ * fire: w is zeroed inside, x = c = 0 outside).  A (lower triangle) is permuted in place; perm_out[k] = original
+ * index of the final row k.  Returns 1 solved, 0 iteration limit reached (the reference returns false) or a
+ * non-positive pivot, -1 allocation failure.  *iters = iterations of the loop. */
+int otk_box_murty(int n, double *A, const double *b, const double *lo, const double *hi, int max_iterations,
+                  double *x, double *w, int *perm_out, int *iters) {
+  double *buf = (double *)calloc((size_t)n * n + 8 * (size_t)n, sizeof(double));
+  int *perm = (int *)malloc(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1));
+  if (!buf || !perm) { free(buf); free(perm); return -1; }
+  int *iperm = perm + n;
+  double *L = buf, *x_ = L + (size_t)n * n, *c = x_ + n, *c2 = c + n, *t = c2 + n, *x2 = t + n, *work = x2 + n;   /* work: 2 n */
+  /* LinearReducer::LinearReducer (:213-224) */
+  for (int r = 0; r < n; ++r)
+    for (int q = 0; q <= r; ++q) AT(L, r, q) = AT(A, r, q);
+  int ok = otk_cholesky(L, n) == 0, index = n, it = 0, solved = 0;
+  for (int i = 0; i < n; ++i) { perm[i] = i; iperm[i] = i; x_[i] = b[i]; c[i] = 0.0; }
+  if (ok) otk_lltsolve(L, n, n, x_);
+  for (; ok && it < max_iterations; ++it) {
+    /* SubSolve (:245-296) */
+    if (index == 0) {
+      for (int i = 0; i < n; ++i) x[i] = c[i];
+    } else if (index >= n) {
+      for (int i = 0; i < n; ++i) x[perm[i]] = x_[i];
+    } else {
+      for (int i = 0; i < n; ++i) c2[i] = c[perm[i]];
+      for (int k = 0; k < index; ++k) {
+        double s = 0.0;
+        for (int r = index; r < n; ++r) s = s + AT(A, r, k) * (c2[r] - x_[r]);
+        t[k] = s;
+      }
+      otk_lltsolve(L, n, index, t);
+      for (int i = 0; i < index; ++i) x[perm[i]] = x_[i] - t[i];
+      for (int i = index; i < n; ++i) x[perm[i]] = c[perm[i]];
+    }
+    /* MultiplyA (:298-322) on the rows outside the set, then w = A x - b there and 0 inside (:396-404) */
+    for (int i = 0; i < n; ++i) x2[i] = x[perm[i]];
+    for (int r = index; r < n; ++r) {
+      double s = 0.0;
+      for (int k = 0; k < index; ++k) s = s + AT(A, r, k) * x2[k];
+      double u = 0.0;
+      for (int k = index; k < n; ++k) u = u + ((k <= r) ? AT(A, r, k) : AT(A, k, r)) * x2[k];
+      w[perm[r]] = (s + u) - b[perm[r]];
+    }
+    for (int i = 0; i < index; ++i) w[perm[i]] = 0.0;
+    /* first violated index in the caller's order (:408-431) */
+    int moved = 0;
+    for (int i = 0; i < n && !moved; ++i) {
+      const int p = iperm[i];
+      if (p < index) {
+        int out = 0;
+        if (x[i] < lo[i]) { c[i] = lo[i]; out = 1; }
+        else if (x[i] > hi[i]) { c[i] = hi[i]; out = 1; }
+        if (out) {      /* RemoveIndex (:236-243) */
+          if (otk_swap_cholesky_rows(A, n, p, index, L, work)) { ok = 0; break; }
+          --index;
+          if (index != p) {
+            const int a = perm[index], bq = perm[p];
+            otk_swap_rows_and_columns(A, n, index, p, perm);
+            iperm[a] = p; iperm[bq] = index;
+            swapd(x_, index, p);
+          }
+          moved = 1;
+        }
+      } else {
+        int in = 0;
+        if (c[i] == lo[i] && w[i] < 0.0) in = 1;
+        else if (c[i] == hi[i] && w[i] > 0.0) in = 1;
+        if (in) {       /* AddIndex (:226-234) */
+          if (index != p) {
+            const int a = perm[index], bq = perm[p];
+            otk_swap_rows_and_columns(A, n, index, p, perm);
+            iperm[a] = p; iperm[bq] = index;
+            swapd(x_, index, p);
+          }
+          ++index;
+          if (otk_add_cholesky_row(A, n, index, L)) { ok = 0; break; }
+          c[i] = 0.0;
+          moved = 1;
+        }
+      }
+    }
+    if (!ok) break;
+    if (!moved) { solved = 1; break; }
+  }
+  for (int k = 0; k < n; ++k) if (perm_out) perm_out[k] = perm[k];
+  if (iters) *iters = it;
+  free(buf); free(perm);
+  return ok && solved;
+}

@@ -335,6 +335,16 @@ def tk_box_dantzig(A, b, lo, hi):
     return ok == 1, x, w, A, perm, piv.value
 
 
+def tk_box_murty(A, b, lo, hi, max_iterations=2**31 - 1):
+    """SolveLCP_BoxMurty on a LinearReducer: returns ok, x, w, A permuted in place, perm, iterations."""
+    A = _f64(A).copy()
+    b, lo, hi = _f64(b), _f64(lo), _f64(hi)
+    n = b.shape[0]
+    x = np.zeros(n); w = np.zeros(n); perm = np.zeros(n, np.int32); it = C.c_int(0)
+    ok = lib().otk_box_murty(C.c_int(n), _p(A), _p(b), _p(lo), _p(hi), C.c_int(max_iterations), _p(x), _p(w), _p(perm), C.byref(it))
+    return ok == 1, x, w, A, perm, it.value
+
+
 # ---- collision ------------------------------------------------------------
 def collide_box_ground(c, R, side=(0.3, 0.3, 0.3)):
     c, R, side = _f64(c), _f64(R), _f64(side)

@@ -85,3 +85,43 @@ def test_refusals_and_limits(ctx):
     ok, *_ = ctx.box_lcp_dantzig(Abad, b, lo, hi)
     oko = orc.tk_box_dantzig(Abad, b, lo, hi)[0]
     assert ok == oko
+
+
+def test_box_murty_on_a_linear_reducer(ctx):      # toolkit/lcp.cc:874-945 restated, and the oracle's steps
+    rng = np.random.default_rng(15)
+    N = 7
+    for it in range(60):
+        A = spd(rng, N, 0.0 if it % 2 else 0.001)
+        b = rng.uniform(-1, 1, N)
+        # standard LCP = box with lo = 0, hi = DBL_MAX (SolveLCP_Murty)
+        lo = np.zeros(N); hi = np.full(N, np.finfo(float).max)
+        ok, x, w, Ap, perm, iters = ctx.box_lcp_murty(np.tril(A), b, lo, hi)
+        assert ok and (x >= 0).all() and (w >= 0).all() and np.all(x * w == 0) and np.linalg.norm(A @ x - b - w) < 1e-6
+        oko, xo, wo, Ao, permo, ito = orc.tk_box_murty(np.tril(A), b, lo, hi)
+        assert iters == ito and np.array_equal(perm, permo) and np.array_equal(np.tril(Ap), np.tril(Ao))
+        assert np.abs(x - xo).max() < 1e-12 and np.abs(w - wo).max() < 1e-12
+        lo = -rng.uniform(0, 1, N) * 10.0; hi = rng.uniform(0, 1, N) * 10.0
+        ok, x, w, Ap, perm, iters = ctx.box_lcp_murty(np.tril(A), b, lo, hi)
+        assert ok
+        check_box_lcp(A, b, lo, hi, x, w)
+        oko, xo, wo, Ao, permo, ito = orc.tk_box_murty(np.tril(A), b, lo, hi)
+        assert iters == ito and np.array_equal(perm, permo) and np.array_equal(np.tril(Ap), np.tril(Ao))
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 96])
+def test_box_murty_sizes_and_limit(ctx, n):
+    rng = np.random.default_rng(300 + n)
+    A = spd(rng, n, 0.05)
+    b = rng.uniform(-2, 2, n)
+    lo = -rng.uniform(0.05, 2, n); hi = rng.uniform(0.05, 2, n)
+    hi[rng.uniform(size=n) < 0.3] = np.inf
+    ok, x, w, Ap, perm, iters = ctx.box_lcp_murty(np.tril(A), b, lo, hi)
+    assert ok
+    check_box_lcp(A, b, lo, hi, x, w)
+    oko, xo, wo, Ao, permo, ito = orc.tk_box_murty(np.tril(A), b, lo, hi)
+    assert oko and iters == ito and np.array_equal(perm, permo)
+    assert np.abs(x - xo).max() < 1e-10 and np.abs(w - wo).max() < 1e-10
+    okd, xd, wd, *_ = ctx.box_lcp_dantzig(np.tril(A), b, lo, hi)           # the other algorithm, same unique solution
+    assert okd and np.abs(x - xd).max() < 1e-8
+    if iters > 1:       # Settings.max_iterations: gives up, returns false (toolkit/lcp.cc:438-441)
+        assert not ctx.box_lcp_murty(np.tril(A), b, lo, hi, max_iterations=iters - 1)[0]

@@ -125,3 +125,45 @@ def test_box_dantzig_agrees_with_the_dense_box_murty():
             check_box_lcp(A, b, lo, hi, x, w)
             ok2, x2, w2, _ = orc.mixed_constraints(A, b, np.zeros(n, np.uint8), lo, hi, 1)     # true box Murty
             assert ok2 and np.abs(x - x2).max() < 1e-8 and np.abs(w - w2).max() < 1e-8
+
+
+def test_box_murty_reference_property_test():      # toolkit/lcp.cc:874-945
+    rng = np.random.default_rng(7)
+    for it in range(1000):
+        A = spd(rng, N)
+        b = rng.uniform(-1, 1, N)
+        # the standard LCP = the box problem with lo = 0, hi = "infinity" (toolkit/lcp.h:149-154)
+        lo = np.zeros(N); hi = np.full(N, np.finfo(float).max)
+        ok, x, w, Ap, perm, iters = orc.tk_box_murty(lower(A), b, lo, hi)
+        assert ok
+        assert (x >= 0).all() and (w >= 0).all() and np.all(x * w == 0)
+        assert np.linalg.norm(A @ x - b - w) < 1e-6
+        assert np.array_equal(np.tril(Ap), np.tril(A[np.ix_(perm, perm)]))
+        # random box
+        lo = -rng.uniform(0, 1, N) * 10.0; hi = rng.uniform(0, 1, N) * 10.0
+        for i in range(N):
+            r = int(rng.integers(0, 100))
+            if r == 0: lo[i] = 0.0
+            elif r == 1: hi[i] = 0.0
+        ok, x, w, Ap, perm, iters = orc.tk_box_murty(lower(A), b, lo, hi)
+        assert ok
+        check_box_lcp(A, b, lo, hi, x, w)
+
+
+def test_box_murty_agrees_with_dantzig_and_the_dense_murty_and_honours_the_limit():
+    rng = np.random.default_rng(8)
+    for n in (1, 3, 10, 33, 64):
+        for _ in range(8):
+            A = spd(rng, n, 0.05)
+            b = rng.uniform(-2, 2, n)
+            lo = -rng.uniform(0.05, 2, n); hi = rng.uniform(0.05, 2, n)
+            hi[rng.uniform(size=n) < 0.3] = np.inf
+            ok, x, w, Ap, perm, iters = orc.tk_box_murty(lower(A), b, lo, hi)
+            assert ok
+            check_box_lcp(A, b, lo, hi, x, w)
+            okd, xd, wd, *_ = orc.tk_box_dantzig(lower(A), b, lo, hi)
+            assert okd and np.abs(x - xd).max() < 1e-8 and np.abs(w - wd).max() < 1e-8
+            ok2, x2, w2, _ = orc.mixed_constraints(A, b, np.zeros(n, np.uint8), lo, hi, 1)
+            assert ok2 and np.abs(x - x2).max() < 1e-8
+            if iters > 1:      # max_iterations: gives up and returns false (toolkit/lcp.cc:438-441)
+                assert not orc.tk_box_murty(lower(A), b, lo, hi, max_iterations=iters - 1)[0]
