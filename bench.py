@@ -425,6 +425,16 @@ def c5_leg(ctx, cpu_seconds):
         out[key] = {"ms_per_solve": ms, "ok": bool(ok), "pivots": int(piv), "kkt_residual": resid,
                     "schur_gflop": flops / 1e9, "achieved_tflops_schur_only": flops / (ms * 1e-3) / 1e12,
                     "includes": "pageable upload of A (%.1f MB) + solve + download" % (A.nbytes / 1e6)}
+    # toolkit/lcp.cc's incremental-factor solvers (one wavefront, everything in LDS, n <= 96): latency only
+    A, b, C, lo, hi = c5_problem(96)
+    lo96 = np.where(C != 0, -np.inf, np.minimum(lo, 0.0)); hi96 = np.where(C != 0, np.inf, np.maximum(hi, 0.5))
+    for name, fn in (("N96_box_dantzig_incremental", ctx.box_lcp_dantzig), ("N96_box_murty_linear_reducer", ctx.box_lcp_murty)):
+        fn(np.tril(A), b, lo96, hi96)
+        t0 = time.perf_counter()
+        ok, x, w, Ap, perm, piv = fn(np.tril(A), b, lo96, hi96)
+        out[name] = {"ms_per_solve": (time.perf_counter() - t0) * 1e3, "ok": bool(ok), "pivots": int(piv),
+                     "kkt_residual": float(np.abs(A @ x - b - w).max()),
+                     "includes": "upload + one single-wavefront launch + download (toolkit/lcp.cc:213-619 semantics, A permuted in place)"}
     out["note"] = ("reference_rule = Murty single-index principal pivoting as lcp.cc:157-274 (cap min(1000, 2^n) pivots: it "
                    "cannot finish N >= 1024 mixed problems, in the reference as here); block_pivoting = same solution, tens of "
                    "factorisations.  Launch-bound at these sizes: ~3 dependent launches per 64-column panel; fp64 MFMA peak is "
