@@ -422,6 +422,9 @@ bool box_lcp_incremental(hipStream_t stream, int algorithm, int n, double *A, co
       throw std::invalid_argument("box_lcp_incremental: needs lo <= 0 <= hi (and lo < hi for Cottle-Dantzig)");
   }
   const size_t nn = (size_t)n * n;
+  // plain hipMalloc / hipFree on purpose: with a stream-ordered pool allocation (hipMallocAsync / hipFreeAsync)
+  // back-to-back calls that got the same block back saw stale lines of the previous call's matrix on this
+  // stack (ROCm 7.2; tests/test_gpu_dantzig.py::test_repeated_calls_are_independent)
   double *dA = nullptr, *dv = nullptr;
   int32_t *dperm = nullptr;
   DantzigResult *dres = nullptr;

@@ -125,3 +125,16 @@ def test_box_murty_sizes_and_limit(ctx, n):
     assert okd and np.abs(x - xd).max() < 1e-8
     if iters > 1:       # Settings.max_iterations: gives up, returns false (toolkit/lcp.cc:438-441)
         assert not ctx.box_lcp_murty(np.tril(A), b, lo, hi, max_iterations=iters - 1)[0]
+
+
+def test_repeated_calls_are_independent(ctx):
+    """Back-to-back calls with the same and with different inputs (device buffers are allocated per call)."""
+    rng = np.random.default_rng(77)
+    for n in (12, 48, 96):
+        A = spd(rng, n, 0.05); b = rng.uniform(-1, 1, n)
+        lo = -np.full(n, 0.2); hi = np.full(n, 0.3)
+        for fn, ofn in ((ctx.box_lcp_dantzig, orc.tk_box_dantzig), (ctx.box_lcp_murty, orc.tk_box_murty)):
+            o = ofn(np.tril(A), b, lo, hi)
+            for rep in range(4):
+                r = fn(np.tril(A), b, lo, hi)
+                assert r[0] and r[5] == o[5] and np.array_equal(r[4], o[4]) and np.array_equal(np.tril(r[3]), np.tril(o[3]))
