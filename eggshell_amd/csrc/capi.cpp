@@ -129,8 +129,10 @@ inline bool iso_schedule_pays(long m, int cu, int precision) {
   if (precision == EGS_F32) return t > 3L * cu;         // fp32: 4 instead of 3 tiles per CU (C4: +7 %)
   if (t < 2L * cu) return false;                       // fewer than two tiles per CU: registers are not the limit
   const long full3 = t / (3L * cu), rem3 = t % (3L * cu);
-  const double iso = 0.66 * full3 + (rem3 == 0 ? 0.0 : rem3 <= cu ? 0.45 : rem3 <= 2L * cu ? 0.57 : 0.66);
-  const double regular = 0.53 * ((t / 2 + cu - 1) / cu);
+  // (timetable kernels: one / two / three isotropic tiles per CU walk a launch in 0.435 / 0.462 / 0.50 ms, a round of
+  //  512-constraint regular tiles in 0.415 ms; the ticket kernels' figures were 0.45 / 0.57 / 0.66 and 0.53 -- same choices)
+  const double iso = 0.50 * full3 + (rem3 == 0 ? 0.0 : rem3 <= cu ? 0.435 : rem3 <= 2L * cu ? 0.462 : 0.50);
+  const double regular = 0.415 * ((t / 2 + cu - 1) / cu);
   return iso < regular;
 }
 
