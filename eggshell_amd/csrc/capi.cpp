@@ -644,7 +644,8 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   if (history) {
     const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
     const size_t per_sweep = (3 * m + 6 * n) * rs;
-    int K = (int)std::min<size_t>(64, std::max<size_t>(1, (size_t(256) << 20) / per_sweep));
+    // up to 64 recorded sweeps per launch within 2 GiB of snapshots (24 C3 piles: 14 MB per sweep)
+    int K = (int)std::min<size_t>(64, std::max<size_t>(1, (size_t(2048) << 20) / per_sweep));
     K = std::min(K, prm->max_iters);
     p->hist_x.alloc((size_t)K * 3 * m * rs);
     p->hist_acc.alloc((size_t)K * 6 * n * rs);

@@ -260,44 +260,66 @@ __global__ void __launch_bounds__(256) residual_partials_kernel(int rows, const 
 // w = cfm x + J a - rhs from the snapshots, evaluated with the solve kernels' own epilogue
 // expression, then the reduction of residual_partials_kernel -- so each sweep's value is the
 // one a launch stopped after that sweep would have produced, bit for bit.
-template <typename REAL>
-__global__ void __launch_bounds__(256) hist_residual_kernel(const SolveArgs<REAL> A, double *out, int write_sweep) {
+// One block walks its rows ONCE per group of G recorded sweeps: the row's J blocks, bounds and rhs are read
+// once and serve G sweeps (per sweep only lambda and the two accumulators change), instead of re-streaming
+// 300 B of J per row and sweep.  Per sweep every thread adds the same rows in the same order and the block
+// reduces them the same way as before, so the sums have the same bits.
+template <typename REAL, int G>
+__global__ void __launch_bounds__(256) hist_residual_kernel(const SolveArgs<REAL> A, double *out, int write_sweep, int sweeps) {
   __shared__ double red[4][256];
-  const int sweep = blockIdx.y;          // 0-based
-  const REAL *hx = A.hist_x + (size_t)sweep * A.m * 3;
-  const REAL *ha = A.hist_acc + (size_t)sweep * A.n_bodies * 6;
+  const int s0 = blockIdx.y * G;          // first sweep of the group, 0-based
   const int rows = 3 * A.m;
-  double e = 0, a = 0, b = 0, c = 0;
+  double acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; acc[g][2] = 0; acc[g][3] = 0; }
   for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
     const int i = r / 3, rr = r - 3 * i;
     const int b0 = A.body0[i], b1 = A.body1[i];
-    REAL j0[6], j1[6], a0[6], a1[6];
+    REAL j0[6], j1[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       j0[k] = b0 >= 0 ? A.J0[(size_t)i * 18 + 6 * rr + k] : REAL(0);
       j1[k] = b1 >= 0 ? A.J1[(size_t)i * 18 + 6 * rr + k] : REAL(0);
-      a0[k] = b0 >= 0 ? ha[(size_t)b0 * 6 + k] : REAL(0);
-      a1[k] = b1 >= 0 ? ha[(size_t)b1 * 6 + k] : REAL(0);
     }
-    const REAL xv = hx[r], l = A.lo[r], h = A.hi[r];
-    const REAL wr = tfma(A.cfm, xv, row_dot(j0, a0, j1, a1)) - A.rhs[r];
-    if (write_sweep == sweep + 1) A.wres[r] = wr;
-    const double w = (double)wr;
-    if (A.is_eq[r]) e += w * w;
-    else {
-      if (xv == l && w < 0) a += w * w;
-      if (xv == h && w > 0) b += w * w;
-      if (xv > l && xv < h) c += w * w;
+    const REAL l = A.lo[r], h = A.hi[r], rhs = A.rhs[r];
+    const bool eq = A.is_eq[r] != 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int sweep = s0 + g;
+      if (sweep >= sweeps) break;
+      const REAL *ha = A.hist_acc + (size_t)sweep * A.n_bodies * 6;
+      REAL a0[6], a1[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        a0[k] = b0 >= 0 ? ha[(size_t)b0 * 6 + k] : REAL(0);
+        a1[k] = b1 >= 0 ? ha[(size_t)b1 * 6 + k] : REAL(0);
+      }
+      const REAL xv = A.hist_x[(size_t)sweep * A.m * 3 + r];
+      const REAL wr = tfma(A.cfm, xv, row_dot(j0, a0, j1, a1)) - rhs;
+      if (write_sweep == sweep + 1) A.wres[r] = wr;
+      const double w = (double)wr;
+      if (eq) acc[g][0] += w * w;
+      else {
+        if (xv == l && w < 0) acc[g][1] += w * w;
+        if (xv == h && w > 0) acc[g][2] += w * w;
+        if (xv > l && xv < h) acc[g][3] += w * w;
+      }
     }
   }
-  red[0][threadIdx.x] = e; red[1][threadIdx.x] = a; red[2][threadIdx.x] = b; red[3][threadIdx.x] = c;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s)
-      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int sweep = s0 + g;
+    if (sweep >= sweeps) break;
     __syncthreads();
+    red[0][threadIdx.x] = acc[g][0]; red[1][threadIdx.x] = acc[g][1]; red[2][threadIdx.x] = acc[g][2]; red[3][threadIdx.x] = acc[g][3];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s)
+        for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) out[((size_t)sweep * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
   }
-  if (threadIdx.x < 4) out[((size_t)sweep * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 // --------------------------------------------------------------------------
@@ -898,7 +920,8 @@ void launch_residual_partials(int rows, const REAL *wres, const REAL *x, const R
 template <typename REAL>
 void launch_hist_residual(const SolveArgs<REAL> &a, int sweeps, int blocks, double *out, int write_sweep, hipStream_t s) {
   if (sweeps <= 0 || a.m <= 0) return;
-  hipLaunchKernelGGL((hist_residual_kernel<REAL>), dim3(blocks, sweeps), dim3(256), 0, s, a, out, write_sweep);
+  constexpr int G = 8;   // recorded sweeps that share one pass over the J blocks
+  hipLaunchKernelGGL((hist_residual_kernel<REAL, G>), dim3(blocks, (sweeps + G - 1) / G), dim3(256), 0, s, a, out, write_sweep, sweeps);
 }
 
 template <typename REAL>
