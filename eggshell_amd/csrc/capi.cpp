@@ -405,14 +405,17 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     a.spin_limit = spin_limit();
     a.iso = (p->minv_iso && !quad && p->plan.block == 256 && iso_schedule_pays(p->m, ctx->cu_count, p->precision)) ? 1 : 0;
     a.n_bodies = p->n;
-    if (p->hist_sweeps > 0) {   // the isotropic variant has no registers to spare for it
+    if (p->hist_sweeps > 0) {
       a.hist_x = reinterpret_cast<REAL *>(p->hist_x.p);
       a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
-      a.iso = 0;
+      // the ticket kernel's isotropic variant has no registers to spare for the snapshots; the timetable
+      // kernel has an instantiation of its own for them
+      if (!(method != EGS_JACOBI && !quad && use_static_timetable(p->plan, sweeps))) a.iso = 0;
     }
     {
       const char *ie = std::getenv("EGS_ISO");   // 2: force the variant wherever the bodies allow it (experiments)
-      if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256 && p->hist_sweeps == 0) a.iso = 1;
+      if (ie && std::atoi(ie) == 2 && p->minv_iso && !quad && p->plan.block == 256 &&
+          (p->hist_sweeps == 0 || (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)))) a.iso = 1;
     }
     p->last_iso = quad ? 0 : a.iso;
     if (quad) {

@@ -36,7 +36,7 @@ __device__ __forceinline__ int timetable_end(int depth, int P, int sweeps, int r
   return n_phases >= 1 ? depth + P * (n_phases - 1) : 0;
 }
 
-template <typename REAL, int BLOCK, int METHOD, bool ISO, int GROUP>
+template <typename REAL, int BLOCK, int METHOD, bool ISO, int GROUP, bool HIST>
 __global__ void __launch_bounds__(BLOCK * GROUP, (ISO && GROUP == 1) ? (sizeof(REAL) == 4 ? 4 : 3) : 1) step_solve_kernel(const SolveArgs<REAL> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WAVES = BLOCK / 64;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(BLOCK * GROUP, (ISO && GROUP == 1) ? (sizeof(R
   }
   const unsigned ac0 = lds_addr(s_acc + slot0 * 6), ac1 = lds_addr(s_acc + slot1 * 6);
   // snapshots for the per-sweep stopping test (kernels.h): is this lane the last update of its body in a sweep?
-  const bool hist = !ISO && A.hist_x != nullptr;
+  const bool hist = HIST && A.hist_x != nullptr;   // isotropic variant: a separate instantiation, the plain one keeps its registers
   const bool last0 = (METHOD == 2) ? d.pos0 == 0 : d.pos0 + 1 == d.cnt0, last1 = (METHOD == 2) ? d.pos1 == 0 : d.pos1 + 1 == d.cnt1;
 
   // the clock runs until the longest timetable of the group has ended
@@ -161,12 +161,13 @@ void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int bl
   if (n_tiles <= 0) return;
   SolveArgs<REAL> b = a;
   b.n_tiles = n_tiles;
-#define EGS_LAUNCH_S(BLK, ISO, GRP)                                                                            \
+#define EGS_LAUNCH_S(BLK, ISO, GRP) EGS_LAUNCH_SH(BLK, ISO, GRP, !ISO)
+#define EGS_LAUNCH_SH(BLK, ISO, GRP, HIST)                                                                     \
   {                                                                                                            \
     const size_t lds = (size_t)b.max_slots * 6 * sizeof(REAL) * GRP;                                           \
     const dim3 g((n_tiles + GRP - 1) / GRP), t(BLK * GRP);                                                     \
-    auto k1 = step_solve_kernel<REAL, BLK, 1, ISO, GRP>;                                                       \
-    auto k2 = step_solve_kernel<REAL, BLK, 2, ISO, GRP>;                                                       \
+    auto k1 = step_solve_kernel<REAL, BLK, 1, ISO, GRP, HIST>;                                                 \
+    auto k2 = step_solve_kernel<REAL, BLK, 2, ISO, GRP, HIST>;                                                 \
     if (lds > 48 * 1024) {                                                                                     \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(method == 1 ? k1 : k2),                            \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
@@ -179,7 +180,8 @@ void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int bl
     // pays for the four fp32 tiles (C4: 0.281 ms against 0.368); with three fp64 tiles the 12-wavefront
     // barrier costs more than the collisions it avoids (C3 x 24: 1.06 ms against 0.95), so fp64 keeps GROUP = 1
     const int grp = step_group_env(sizeof(REAL) == 4 ? 4 : 1);
-    if constexpr (sizeof(REAL) == 4) {
+    if (b.hist_x != nullptr) EGS_LAUNCH_SH(256, true, 1, true)      // per-sweep snapshots of the stopping loop (kernels.h)
+    else if constexpr (sizeof(REAL) == 4) {
       if (grp >= 4) EGS_LAUNCH_S(256, true, 4)
       else if (grp >= 2) EGS_LAUNCH_S(256, true, 2)
       else EGS_LAUNCH_S(256, true, 1)
@@ -193,6 +195,7 @@ void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int bl
   else if (block == 64) EGS_LAUNCH_S(64, false, 1)
   else EGS_LAUNCH_S(512, false, 1)
 #undef EGS_LAUNCH_S
+#undef EGS_LAUNCH_SH
 }
 
 template void launch_step_solve<double>(const SolveArgs<double> &, int, int, int, hipStream_t);
