@@ -451,6 +451,31 @@ def c5_leg(ctx, cpu_seconds):
     return out
 
 
+def stopping_loop_leg(ctx):
+    """The reference's own iteration loop (sparse_iterations.cc:204-221: residual after every sweep, stop at
+    err <= 1e-9 or after 500 sweeps) on C3: these piles do not converge in 500 sweeps, so this is the cost of
+    500 sweeps WITH the per-sweep stopping test, which the library evaluates from recorded snapshots."""
+    nx, ny, nz, sweeps, prec, dt = WORKLOADS["c3"]
+    out = {}
+    for piles in (1, 24):
+        sc = scenes.concat([scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=k + 1, origin=(0.0, 100.0 * k)) for k in range(piles)]) \
+            if piles > 1 else scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=1)
+        pr, _ = build_problem(ctx, sc, capi.F64)
+        pr.assemble(dt, 0.2)
+        prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=500, tol=1e-9, cfm=0.01)
+        st = pr.solve(prm)
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st = pr.solve(prm)
+            best = min(best, time.perf_counter() - t0)
+        out["c3_x%d" % piles] = {"ms_per_solve": best * 1e3, "sweeps": int(st.iterations), "residual": float(st.residual),
+                                 "us_per_sweep": best * 1e6 / max(int(st.iterations), 1)}
+        pr.close()
+    out["note"] = "tol 1e-9, cap 500, residual evaluated after every sweep (host-synchronous once per 64 recorded sweeps)"
+    return out
+
+
 def c1_leg(ctx, cpu_seconds):
     """BASELINE config 1: the single Chain ensemble of ensembles.cc (8 bodies, 7 ball joints + the anchor),
     fp64 -- the reference's own CPU-runnable case.  Through the GPU library: the iterative path with the
@@ -593,7 +618,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"], help="the headline workload (`value`)")
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
-    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal (1 GPU only)")
+    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal,stopping_loop (1 GPU only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -611,7 +636,7 @@ def main():
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
     legs = set() if (args.legs == "none" or world > 1) else \
-        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal"} if args.legs == "all" else set(args.legs.split(",")))
+        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal", "stopping_loop"} if args.legs == "all" else set(args.legs.split(",")))
 
     if args.workload == "c4":     # BASELINE config 4: 1024 ensembles sharded over the ranks
         seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
@@ -688,6 +713,8 @@ def main():
             extra["coupled"] = coupled_leg(ctx, method, max(5, args.steps // 2), 2, min(5.0, args.cpu_seconds))
         if "c5" in legs:
             extra["c5"] = c5_leg(ctx, args.cpu_seconds)
+        if "stopping_loop" in legs:
+            extra["stopping_loop"] = stopping_loop_leg(ctx)
         out.update(extra)
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
