@@ -647,9 +647,12 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   if (history) {
     const size_t rs = p->real_size(), m = (size_t)p->m, n = (size_t)(p->n > 0 ? p->n : 1);
     const size_t per_sweep = (3 * m + 6 * n) * rs;
-    // up to 64 recorded sweeps per launch within 2 GiB of snapshots (24 C3 piles: 14 MB per sweep)
-    int K = (int)std::min<size_t>(64, std::max<size_t>(1, (size_t(2048) << 20) / per_sweep));
+    // up to 256 recorded sweeps per launch within 2 GiB of snapshots (24 C3 piles: 14 MB per sweep).  The first
+    // launch records at most 64 and every further one twice as many as the one before: a solve that converges
+    // early wastes little, a long one pays the timetable's fill and the read-back once per 256 sweeps
+    int K = (int)std::min<size_t>(256, std::max<size_t>(1, (size_t(2048) << 20) / per_sweep));
     K = std::min(K, prm->max_iters);
+    int k_cur = std::min(K, 64);
     p->hist_x.alloc((size_t)K * 3 * m * rs);
     p->hist_acc.alloc((size_t)K * 6 * n * rs);
     p->hist_out.alloc((size_t)K * kResidualBlocks * 4);
@@ -657,7 +660,8 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     HIPCHK(hipMemsetAsync(p->hist_acc.p, 0, (size_t)K * 6 * n * rs, ctx->stream));
     std::vector<double> part((size_t)K * kResidualBlocks * 4);
     while (!flag && err > prm->tol && it < prm->max_iters) {
-      const int chunk = std::min(K, prm->max_iters - it);
+      const int chunk = std::min(k_cur, prm->max_iters - it);
+      k_cur = std::min(2 * k_cur, K);
       p->hist_sweeps = chunk;
       launch_solve(p, *prm, chunk, 1);
       p->hist_sweeps = 0;
