@@ -453,6 +453,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
   int due = (METHOD == 2 && A.resume) ? depth - 1 - level : level;
   if (!active || sweep > A.sweeps) due = 0x7fffffff;
 
+  REAL snap[3] = {REAL(0), REAL(0), REAL(0)};
   // one update of this lane's constraint: `an` = its quarter of the body's accumulator, in and out
   auto update = [&](REAL (&an)[3]) {
     REAL dx[3] = {REAL(0), REAL(0), REAL(0)};
@@ -501,7 +502,12 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
         an[k] = tfma(Bh[3 * k + 2], dx[2], u);
       }
     }
-    if (HIST && sweep >= 1) {   // snapshots for the per-sweep stopping test (kernels.h)
+    if (HIST) { snap[0] = an[0]; snap[1] = an[1]; snap[2] = an[2]; }   // the accumulator right after THIS update
+  };
+  // snapshots for the per-sweep stopping test (kernels.h), once per time step: every constraint of a group has
+  // had its one update by then, so lambda and the accumulator copy taken in update() are those of this sweep
+  auto record = [&]() {
+    if (HIST && sweep >= 1) {
       if (q == 0) {
         REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
         hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
@@ -509,7 +515,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
       if (has && last_of_body) {   // this was the body's last update of the sweep
         const int body = slot_body[slot];
         REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
-        ha[0] = an[0]; ha[1] = an[1]; ha[2] = an[2];
+        ha[0] = snap[0]; ha[1] = snap[1]; ha[2] = snap[2];
       }
     }
   };
@@ -545,6 +551,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
         }
         if (has && run_pos == 0) store3(acc_addr, an);
       }
+      record();
       due = (METHOD == 2 && sweep == 0) ? t0 + (depth - 1 - level) : due + P;
       if (++sweep > A.sweeps) due = 0x7fffffff;
     }
