@@ -472,7 +472,7 @@ def stopping_loop_leg(ctx):
         out["c3_x%d" % piles] = {"ms_per_solve": best * 1e3, "sweeps": int(st.iterations), "residual": float(st.residual),
                                  "us_per_sweep": best * 1e6 / max(int(st.iterations), 1)}
         pr.close()
-    out["note"] = "tol 1e-9, cap 500, residual evaluated after every sweep (host-synchronous once per 64 recorded sweeps)"
+    out["note"] = "tol 1e-9, cap 500, residual evaluated after every sweep (from snapshots: one host synchronisation per launch of 64, 128, then 256 recorded sweeps)"
     return out
 
 
