@@ -239,6 +239,8 @@ struct egs_problem {
   // [1]: scratch word of the isotropy check.
   DevBuf<int32_t> error_flag;
   int32_t *h_flag = nullptr;   // page-locked copy of [0], refreshed by an async copy after every solve
+  double *h_hist = nullptr;    // page-locked landing area of the stopping loop's per-sweep residual sums (+ the flag)
+  size_t h_hist_cap = 0;       // in doubles
   // per-sweep history of a chunk of sweeps (tolerance-terminated solves, see kernels.h)
   DevBuf<unsigned char> hist_x, hist_acc;
   DevBuf<double> hist_out;
@@ -658,7 +660,16 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     p->hist_out.alloc((size_t)K * kResidualBlocks * 4);
     // bodies without constraints never get a snapshot written: theirs stays zero
     HIPCHK(hipMemsetAsync(p->hist_acc.p, 0, (size_t)K * 6 * n * rs, ctx->stream));
-    std::vector<double> part((size_t)K * kResidualBlocks * 4);
+    // read-backs land in page-locked memory: a pageable destination makes each of the two copies per launch a
+    // synchronous bounce through the runtime's staging buffer
+    const size_t part_len = (size_t)K * kResidualBlocks * 4;
+    if (p->h_hist_cap < part_len + 1) {
+      if (p->h_hist) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(p->h_hist); p->h_hist = nullptr; p->h_hist_cap = 0; }
+      HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->h_hist), (part_len + 1) * sizeof(double), hipHostMallocDefault));
+      p->h_hist_cap = part_len + 1;
+    }
+    double *part = p->h_hist;
+    int32_t *h_f32 = reinterpret_cast<int32_t *>(p->h_hist + part_len);
     while (!flag && err > prm->tol && it < prm->max_iters) {
       const int chunk = std::min(k_cur, prm->max_iters - it);
       k_cur = std::min(2 * k_cur, K);
@@ -677,11 +688,10 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
         }
       };
       residual_pass(0);
-      int32_t f32 = 0;
-      HIPCHK(hipMemcpyAsync(part.data(), p->hist_out.p, (size_t)chunk * kResidualBlocks * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(&f32, p->error_flag.p, sizeof f32, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(part, p->hist_out.p, (size_t)chunk * kResidualBlocks * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(h_f32, p->error_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
-      flag = f32;
+      flag = *h_f32;
       if (flag) { HIPCHK(hipMemsetAsync(p->error_flag.p, 0, sizeof(int32_t), ctx->stream)); break; }
       int stop = 0;   // first recorded sweep (1-based) at which the reference would stop
       double err_stop = 0, err_last = err;
@@ -689,7 +699,7 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
         const bool checked = ((it + sw) % every == 0) || (it + sw == prm->max_iters);
         if (!checked) continue;
         double sum[4] = {0, 0, 0, 0};
-        const double *ps = part.data() + (size_t)(sw - 1) * kResidualBlocks * 4;
+        const double *ps = part + (size_t)(sw - 1) * kResidualBlocks * 4;
         for (int b = 0; b < kResidualBlocks; ++b)
           for (int k = 0; k < 4; ++k) sum[k] += ps[4 * b + k];
         const double e = std::sqrt(sum[0]) + (std::sqrt(sum[1]) + std::sqrt(sum[2]) + std::sqrt(sum[3]));
@@ -1195,6 +1205,7 @@ void egs_problem_destroy(egs_problem *p) {
   if (!p) return;
   if (p->ctx && p->ctx->stream) (void)hipStreamSynchronize(p->ctx->stream);
   if (p->h_flag) (void)hipHostFree(p->h_flag);
+  if (p->h_hist) (void)hipHostFree(p->h_hist);
   delete p;
 }
 
