@@ -451,6 +451,35 @@ def c5_leg(ctx, cpu_seconds):
     return out
 
 
+def world_leg(ctx, steps=30):
+    """SURVEY 8(f) rows 1-3: Ensemble::Step() resident on the device (egs_world: contact generation with the
+    uniform-grid broad phase -> re-plan only when the contact topology changed -> assemble -> 100 GS sweeps ->
+    velocity -> position integration), one C3 pile under gravity, body state never leaves the GPU."""
+    nx, ny, nz, sweeps, prec, dt = WORKLOADS["c3"]
+    sc = scenes.box_stack(nx, ny, nz, jitter=1e-3, seed=1)
+    Minv, f_ext = host_mass_and_force(sc)
+    n = sc["p"].shape[0]
+    w = capi.World(ctx, n)
+    w.set_bodies(sc["p"], sc["R"], sc["v"], sc["w"], Minv, f_ext)
+    prm = capi.params(method=capi.GAUSS_SEIDEL, max_iters=sweeps, tol=0.0, cfm=0.01)
+    for _ in range(3):
+        w.step(dt, 0.2, prm)
+    r0 = w.info()["replans"]
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step(dt, 0.2, prm)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    info = w.info()
+    st = w.step(dt, 0.2, prm, want_stats=True)
+    w.close()
+    return {"value": steps / el, "unit": "world-steps/s", "ms_per_step": el / steps * 1e3, "bodies": n, "contacts": info["n_contacts"],
+            "replans_in_timed_steps": info["replans"] - r0, "sweeps": sweeps, "failed": st.status != capi.OK,
+            "note": "collide + (re-plan on change) + assemble + solve + velocity + positions per step, host sees 8 B per contact of "
+                    "topology per step; the solve alone is the `single_pile` leg"}
+
+
 def stopping_loop_leg(ctx):
     """The reference's own iteration loop (sparse_iterations.cc:204-221: residual after every sweep, stop at
     err <= 1e-9 or after 500 sweeps) on C3: these piles do not converge in 500 sweeps, so this is the cost of
@@ -618,7 +647,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"], help="the headline workload (`value`)")
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
-    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal,stopping_loop (1 GPU only)")
+    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal,stopping_loop,world (1 GPU only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -636,7 +665,7 @@ def main():
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
     legs = set() if (args.legs == "none" or world > 1) else \
-        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal", "stopping_loop"} if args.legs == "all" else set(args.legs.split(",")))
+        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal", "stopping_loop", "world"} if args.legs == "all" else set(args.legs.split(",")))
 
     if args.workload == "c4":     # BASELINE config 4: 1024 ensembles sharded over the ranks
         seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
@@ -715,6 +744,8 @@ def main():
             extra["c5"] = c5_leg(ctx, args.cpu_seconds)
         if "stopping_loop" in legs:
             extra["stopping_loop"] = stopping_loop_leg(ctx)
+        if "world" in legs:
+            extra["world_step"] = world_leg(ctx)
         out.update(extra)
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
