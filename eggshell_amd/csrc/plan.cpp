@@ -282,7 +282,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     if (by_phase) {
       // period of an island = the largest per-body count in it: one pass over the bodies
       // (a body's island is the island of the first constraint that touched it)
-      std::vector<int32_t> last(n_bodies, 0), isl_period(plan.n_islands, 1), body_island(n_bodies, -1);
+      std::vector<int32_t> isl_period(plan.n_islands, 1), body_island(n_bodies, -1);
       for (int i = 0; i < m; ++i) {
         if (body0[i] >= 0 && body_island[body0[i]] < 0) body_island[body0[i]] = cons_island[i];
         if (body1[i] >= 0 && body_island[body1[i]] < 0) body_island[body1[i]] = cons_island[i];
@@ -291,13 +291,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
       for (int b = 0; b < n_bodies; ++b)
         if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], cnt[b] / grp);
       for (int i = 0; i < m; i += grp) {
-        const int b0 = body0[i], b1 = body1[i];
-        int lv = 0;
-        if (b0 >= 0) lv = last[b0];
-        if (b1 >= 0) lv = std::max(lv, last[b1]);
-        if (b0 >= 0) last[b0] = lv + 1;
-        if (b1 >= 0) last[b1] = lv + 1;
-        const int ph = lv % isl_period[cons_island[i]];
+        const int ph = level[i] % isl_period[cons_island[i]];     // the levels computed above
         for (int k = 0; k < grp; ++k) phase[i + k] = ph;
         max_phase = std::max(max_phase, ph);
       }
