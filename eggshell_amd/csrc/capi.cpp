@@ -1074,9 +1074,9 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
       const char *qe = std::getenv("EGS_QUAD_TILE");   // experiment knob: force 64 or 256
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
-      // runs (plan.h) while there is about one 64-constraint tile per CU
+      // runs (plan.h) while there is about one tile per CU
       p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq,
-                            (long)m <= 64L * p->ctx->cu_count);
+                            p->ctx->cu_count);
       bool one_round = true;
       if (force != 1 && p->planq.global.empty()) {
         const size_t qlds = (size_t)p->planq.max_slots * 6 * p->real_size();
@@ -1683,7 +1683,7 @@ egs_status egs_debug_plan_timetable(int32_t n, int32_t m, const int32_t *body0, 
                                     int32_t *level, int32_t *period, int32_t *depth, int32_t *runs) {
   if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
   try {
-    const Plan pl = build_plan(n, m, body0, body1, tile_size, nullptr, tile_size == 0);
+    const Plan pl = build_plan(n, m, body0, body1, tile_size, nullptr, tile_size == 0 ? (1 << 30) : 0);
     if (!pl.levels_ok) return EGS_ERR_INVALID;
     if (runs) *runs = pl.runs ? 1 : 0;
     for (int i = 0; i < m; ++i) {

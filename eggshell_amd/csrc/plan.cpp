@@ -158,7 +158,7 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
 }  // namespace
 
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
-                int block, Plan *recycle, bool allow_runs) {
+                int block, Plan *recycle, int max_run_tiles) {
   if (n_bodies < 0 || m < 0 || block < 0 || block > 1024)
     throw std::invalid_argument("build_plan: bad sizes");
   Plan plan;
@@ -177,6 +177,41 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     if (body0[i] < -1 || body0[i] >= n_bodies || body1[i] < -1 || body1[i] >= n_bodies)
       throw std::invalid_argument("build_plan: body index out of range");
   }
+
+  // runs (plan.h): maximal stretches of consecutive constraints on the same two bodies, cut into chunks of at
+  // most four.  A chunk takes four lane slots (members first, then placeholders that only pass the accumulators
+  // along), so it is one DPP row of the 4-lane kernel; worth it while the padding stays below a quarter.
+  std::vector<int32_t> chunk_of, chunk_first, chunk_len;
+  {
+    const char *env = std::getenv("EGS_RUNS");
+    if (block == kAutoQuadBlock && max_run_tiles > 0 && !(env && std::atoi(env) == 0) && m > 0) {
+      chunk_of.resize(m);
+      for (int i = 0; i < m; ++i) {
+        const bool same = i > 0 && body0[i] == body0[i - 1] && body1[i] == body1[i - 1] && chunk_len.back() < 4;
+        if (!same) { chunk_first.push_back(i); chunk_len.push_back(0); }
+        chunk_of[i] = (int32_t)chunk_len.size() - 1;
+        ++chunk_len.back();
+      }
+      plan.runs = 4L * (long)chunk_len.size() <= (5L * m) / 4;
+      if (plan.runs && !(env && std::atoi(env) == 2)) {
+        // a time step of chunks runs four update passes whatever the chunks hold (0.22 us per pass against 0.29 us
+        // per single-update step), so the busiest body's constraints must come in full chunks: with one short
+        // chunk more (columns that touch sideways in a settling pile: 3 chunks for 10 constraints) it is break-even
+        // at best (world step 0.91 -> 0.94 ms); EGS_RUNS=2 skips this test (experiments, tests)
+        std::vector<int32_t> per_body_c(n_bodies, 0), per_body_n(n_bodies, 0);
+        for (size_t c = 0; c < chunk_len.size(); ++c) {
+          const int i = chunk_first[c];
+          for (int b : {body0[i], body1[i] != body0[i] ? body1[i] : -1})
+            if (b >= 0) { per_body_c[b] += chunk_len[c]; ++per_body_n[b]; }
+        }
+        int maxc = 1, maxn = 1;
+        for (int b = 0; b < n_bodies; ++b) { maxc = std::max(maxc, per_body_c[b]); maxn = std::max(maxn, per_body_n[b]); }
+        plan.runs = 4L * maxn <= (long)maxc;
+      }
+      if (!plan.runs) { chunk_of.clear(); chunk_first.clear(); chunk_len.clear(); }
+    }
+  }
+  const int n_chunks = (int)chunk_len.size();
 
   // 1. islands: union bodies that share a constraint.
   UnionFind uf(n_bodies);
@@ -206,6 +241,20 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   }
   plan.n_islands = (int)island_size.size();
   const bool quad_plan = block == kAutoQuadBlock;
+  if (plan.runs) {   // lane slots, not constraints: four per chunk
+    std::vector<int32_t> padded(island_size.size(), 0);
+    for (int c = 0; c < n_chunks; ++c) padded[cons_island[chunk_first[c]]] += 4;
+    int largest = 0;
+    long total = 0;
+    for (int sz : padded) { largest = std::max(largest, sz); total += sz; }
+    const int blk = largest <= 64 ? 64 : (largest <= 128 ? 128 : 256);
+    int largest_plain = 0;
+    for (int sz : island_size) largest_plain = std::max(largest_plain, sz);
+    // runs pay while a CU holds about one tile (a chunk keeps a quarter of its wavefront's lanes busy); and the
+    // padding must not push an island that fits a workgroup onto the cross-workgroup path
+    if ((total + blk - 1) / blk <= (long)max_run_tiles && !(largest > 256 && largest_plain <= 256)) island_size.swap(padded);
+    else { plan.runs = false; chunk_of.clear(); chunk_first.clear(); chunk_len.clear(); }
+  }
   if (quad_plan) {
     int largest = 0;
     for (int sz : island_size) largest = std::max(largest, sz);
@@ -251,29 +300,25 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   int max_phase = 0;
   // levels of the list-order dependency DAG (plan.h) and every body's span of levels
   std::vector<int32_t> level(m, 0), first_lvl(n_bodies, -1), last_lvl(n_bodies, -1);
-  // runs (plan.h): every aligned group of four constraints joins the same two bodies
-  {
-    const char *env = std::getenv("EGS_RUNS");
-    // (4-lane plans and on request only: a group's four updates keep 1/4 of its wavefront's lanes busy, which
-    //  is fine where the chain latency sets the time and costs passes where throughput does -- one C3 pile
-    //  on the 4-lane kernel: 0.260 -> 0.216 ms, two piles 0.271 -> 0.276, four 0.328 -> 0.364; C3 x 24 on
-    //  the 1-lane kernel: 1.00 -> 1.25 ms)
-    bool runs = quad_plan && allow_runs && !(env && std::atoi(env) == 0) && m > 0 && m % 4 == 0;
-    for (int i = 0; runs && i < m; ++i)
-      if ((i & 3) != 0 && (body0[i] != body0[i - 1] || body1[i] != body1[i - 1])) runs = false;
-    plan.runs = runs;
-  }
-  const int grp = plan.runs ? 4 : 1;   // constraints per node of the level DAG
+  // nodes of the level DAG: constraints, or chunks of a run (plan.h)
+  std::vector<int32_t> node_cnt;      // runs: chunks per body (the ticket period counts constraints, this one nodes)
   {
     std::vector<int32_t> nxt(n_bodies, 0);
-    for (int i = 0; i < m; i += grp) {
+    if (plan.runs) node_cnt.assign(n_bodies, 0);
+    const int nodes = plan.runs ? n_chunks : m;
+    for (int q = 0; q < nodes; ++q) {
+      const int i = plan.runs ? chunk_first[q] : q, len = plan.runs ? chunk_len[q] : 1;
       const int b0 = body0[i], b1 = body1[i];
       int lv = 0;
       if (b0 >= 0) lv = nxt[b0];
       if (b1 >= 0) lv = std::max(lv, nxt[b1]);
-      for (int k = 0; k < grp; ++k) level[i + k] = lv;
+      for (int k = 0; k < len; ++k) level[i + k] = lv;
       for (int b : {b0, b1})
         if (b >= 0) { nxt[b] = lv + 1; if (first_lvl[b] < 0) first_lvl[b] = lv; last_lvl[b] = lv; }
+      if (plan.runs) {
+        if (b0 >= 0) ++node_cnt[b0];
+        if (b1 >= 0 && b1 != b0) ++node_cnt[b1];
+      }
     }
   }
   {
@@ -287,12 +332,12 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
         if (body0[i] >= 0 && body_island[body0[i]] < 0) body_island[body0[i]] = cons_island[i];
         if (body1[i] >= 0 && body_island[body1[i]] < 0) body_island[body1[i]] = cons_island[i];
       }
-      // (with runs: in groups of four -- a body's constraints come in whole groups)
+      // (with runs: in chunks)
       for (int b = 0; b < n_bodies; ++b)
-        if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], cnt[b] / grp);
-      for (int i = 0; i < m; i += grp) {
+        if (body_island[b] >= 0) isl_period[body_island[b]] = std::max(isl_period[body_island[b]], plan.runs ? node_cnt[b] : cnt[b]);
+      for (int i = 0; i < m; ++i) {
         const int ph = level[i] % isl_period[cons_island[i]];     // the levels computed above
-        for (int k = 0; k < grp; ++k) phase[i + k] = ph;
+        phase[i] = ph;
         max_phase = std::max(max_phase, ph);
       }
     }
@@ -332,6 +377,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   plan.tile_slot_off.assign(plan.n_tiles, 0);
   std::vector<int32_t> lane_fill(plan.n_tiles, 0);
   std::vector<int32_t> body_slot(n_bodies, -1), body_tile(n_bodies, -1);
+  std::vector<int32_t> lane_src;      // runs: the constraint whose bodies a lane slot (member or placeholder) belongs to
+  if (plan.runs) lane_src.assign((size_t)plan.n_tiles * block, -1);
 
   // (bank-aware slot numbering, below) body -> where its uses sit inside its tile, CSR over the
   // bodies in rank order; a use = (half-wave << 2 | b128 pass of the half-wave << 1 | side)
@@ -368,6 +415,19 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
       if (b0 >= 0) use_lane[use_off[b0] + pos0[i]] = where;
       if (b1 >= 0 && b1 != b0) use_lane[use_off[b1] + pos1[i]] = where | 1;
     }
+    if (plan.runs) {
+      lane_src[(size_t)tile * block + l] = i;
+      const int c = chunk_of[i];
+      if (i == chunk_first[c] + chunk_len[c] - 1)      // the chunk's last member: fill its row of four
+        for (int pad = chunk_len[c]; pad < 4; ++pad) {
+          const int lp = lane_fill[tile]++;
+          LaneDesc ph{};
+          ph.cidx = -2;                                  // placeholder: in the chain, no constraint
+          plan.lanes[(size_t)tile * block + lp] = ph;
+          plan.lane_level[(size_t)tile * block + lp] = plan.lane_level[(size_t)tile * block + l];
+          lane_src[(size_t)tile * block + lp] = i;
+        }
+    }
   }
   // LDS slots.  A slot's number decides its banks: the ticket word s_tick[slot] is polled with
   // ds_read_b32 (bank = slot mod 32, the 32 lanes of a half-wave share a pass) and the 48-byte
@@ -389,7 +449,8 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
       if (!colour) {
         for (int l = 0; l < nl; ++l)
           for (int side = 0; side < 2; ++side) {
-            const int body = side ? body1[L[l].cidx] : body0[L[l].cidx];
+            const int src = plan.runs ? lane_src[(size_t)t * block + l] : L[l].cidx;
+            const int body = side ? body1[src] : body0[src];
             if (body >= 0 && body_slot[body] < 0) { body_slot[body] = plan.tile_nslots[t]++; body_tile[body] = t; }
           }
       } else {
@@ -444,7 +505,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
         plan.tile_nslots[t] = top + 1;
       }
       for (int l = 0; l < nl; ++l) {
-        const int c = L[l].cidx;
+        const int c = plan.runs ? lane_src[(size_t)t * block + l] : L[l].cidx;
         L[l].slot0 = body0[c] >= 0 ? (uint16_t)body_slot[body0[c]] : 0;
         L[l].slot1 = body1[c] >= 0 ? (uint16_t)body_slot[body1[c]] : 0;
       }

@@ -48,14 +48,14 @@ struct Plan {
   std::vector<int32_t> tile_depth;    // per tile: largest level + 1
   int max_period = 1, max_depth = 1;
   bool levels_ok = true;              // false if a level does not fit 16 bits
-  // Runs: every aligned group of four consecutive constraints (4g .. 4g+3) joins the SAME two bodies --
-  // the four contact points of a box face, as the collider lists them.  Such a group is consecutive in
-  // both bodies' lists, so the timetable can treat it as ONE node whose four updates hand the two
-  // accumulators from lane to lane (DPP) instead of through LDS and a barrier.  With runs = true,
-  // lane_level / tile_period / tile_depth count groups (macro steps of four updates), the lanes of a
-  // group are adjacent and aligned to 4 in their tile, and a lane's place in its group is lane mod 4.
-  // Only 4-lane plans built with allow_runs (a group keeps 1/4 of its wavefront's lanes busy: worth it
-  // where the chain latency sets the time, i.e. about one tile per CU).
+  // Runs: a stretch of consecutive constraints on the SAME two bodies -- the contact points of a box face, as the
+  // collider lists them -- is consecutive in both bodies' lists, so the timetable can treat up to four of them (a
+  // chunk) as ONE node whose updates hand the two accumulators from lane to lane (DPP) instead of through LDS and a
+  // barrier.  With runs = true, lane_level / tile_period / tile_depth count chunks (macro steps of up to four
+  // updates); a chunk owns four adjacent lane slots aligned to 4 in its tile -- its members in list order, then
+  // placeholders (cidx = -2: the chunk's slots and level, no constraint) -- and a lane's place in its chunk is
+  // lane mod 4.  Only 4-lane plans built with max_run_tiles > 0, needing at most that many tiles, and with less than a quarter of padding (a chunk keeps
+  // 1/4 of its wavefront's lanes busy: worth it where the chain latency sets the time, about one tile per CU).
   bool runs = false;
   std::vector<int32_t> tile_nslots;   // per tile, slots in use (slot 0 = world)
   std::vector<int32_t> tile_slot_off; // per tile, offset into slot_body
@@ -87,6 +87,6 @@ constexpr int kAutoQuadBlock = 0;
 // recycle: a plan that is no longer needed; its vectors' storage is reused (a world re-plans on
 // every contact-topology change: the 16 B/lane table alone is a fresh 270 KB mapping otherwise).
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
-                int block, Plan *recycle = nullptr, bool allow_runs = false);
+                int block, Plan *recycle = nullptr, int max_run_tiles = 0);
 
 }  // namespace egs

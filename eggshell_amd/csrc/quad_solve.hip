@@ -400,8 +400,11 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
 
   const LaneDesc d = A.lanes[(size_t)tile * QT + (tid >> 2)];
   const bool active = d.cidx >= 0;
+  // RUNS: a chunk of fewer than four constraints is padded with placeholders (cidx = -2, plan.h): they have the
+  // chunk's slots and level, take part in the hand-off of the accumulator and update nothing
+  const bool chain = RUNS ? d.cidx != -1 : active;
   const int slot = side ? d.slot1 : d.slot0;
-  const bool has = active && slot != 0;            // this lane's body is a real body
+  const bool has = chain && slot != 0;             // this lane's body is a real body
   const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
   REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
   const int level = A.lane_level[(size_t)tile * QT + (tid >> 2)];
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
   int sweep = A.resume ? 1 : 0;
   const int t0 = (METHOD == 2 && !A.resume) ? depth : 0;       // backward sweeps start after the forward accumulation
   int due = (METHOD == 2 && A.resume) ? depth - 1 - level : level;
-  if (!active || sweep > A.sweeps) due = 0x7fffffff;
+  if (!chain || sweep > A.sweeps) due = 0x7fffffff;
 
   REAL snap[3] = {REAL(0), REAL(0), REAL(0)};
   // one update of this lane's constraint: `an` = its quarter of the body's accumulator, in and out
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
   // snapshots for the per-sweep stopping test (kernels.h), once per time step: every constraint of a group has
   // had its one update by then, so lambda and the accumulator copy taken in update() are those of this sweep
   auto record = [&]() {
-    if (HIST && sweep >= 1) {
+    if (HIST && sweep >= 1 && active) {
       if (q == 0) {
         REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
         hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
 #pragma unroll
             for (int k = 0; k < 3; ++k) an[k] = dpp<0x114>(an[k]);
           }
-          if (run_pos == sub) update(an);
+          if (run_pos == sub && active) update(an);
         }
         if (has && run_pos == 3) store3(acc_addr, an);
       } else {
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(4 * QT) step_quad_kernel(const SolveArgs<REAL>
 #pragma unroll
             for (int k = 0; k < 3; ++k) an[k] = dpp<0x104>(an[k]);
           }
-          if (run_pos == 3 - sub) update(an);
+          if (run_pos == 3 - sub && active) update(an);
         }
         if (has && run_pos == 0) store3(acc_addr, an);
       }

@@ -138,8 +138,10 @@ def random_system(rng, n, m, world_frac=0.2, eq_frac=0.4, connected=False):
 def grouped_system(rng, s, rhs, rep=4):
     """Every constraint of `s` `rep` times in a row with fresh J blocks, bounds and right-hand sides:
     the shape of a box face's contact points (the 4-lane plan treats aligned groups of four as runs)."""
-    m = s.body0.shape[0] * rep
+    if rep == "ragged":      # 1..4 contact points per pair, mostly 4: what a collider leaves after pruning
+        rep = rng.choice([1, 2, 3, 4, 4, 4, 4, 4, 4, 5, 8], size=s.body0.shape[0])
     body0, body1 = np.repeat(s.body0, rep), np.repeat(s.body1, rep)
+    m = body0.shape[0]
     J0 = rng.uniform(-1, 1, (m, 18)); J1 = rng.uniform(-1, 1, (m, 18))
     J0[body0 < 0] = 0.0; J1[body1 < 0] = 0.0
     is_eq = np.repeat(s.is_eq.reshape(-1, 3), rep, axis=0).reshape(-1)
