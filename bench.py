@@ -28,6 +28,7 @@ the kernels the north star names, each with the physical bound that applies:
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
       --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no launcher: bench.py starts its own N ranks)
 
 Multi-GPU: one process per GPU, no data-path collective; RCCL carries one
 statistics reduction per run.
@@ -638,6 +639,60 @@ def cpu_literal_baseline(budget_s):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them), BEFORE any
+    GPU call in this process -- children are started with subprocess, never exec'd from a process that touched the
+    GPU.  Rank 0 prints the one JSON line on the inherited stdout; any rank failing ends the others and the exit
+    code is non-zero."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:          # one rank failed: the others would wait for it at the barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """The N > 1 plumbing without a GPU: rendezvous, the shard of this rank (the same functions the real run uses),
+    one statistics reduction, rank 0 prints the line.  No solve, no timing claim."""
+    import torch.distributed as tdist
+    if world > 1:
+        egs_dist.init_process_group(args.dist_backend)
+    if args.workload == "c4":
+        seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
+    else:
+        seeds, scaling, unit = [rank * args.batch + b + 1 for b in range(args.batch)], "weak", "pile-steps/s"
+    el, units, citers, resid, failed = egs_dist.reduce_stats(1.0 + 0.25 * rank, len(seeds) * args.steps, 0.0, 0.0, False)
+    if world > 1:
+        tdist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "constraint_solve_steps_per_sec", "dry_run": True, "value": None, "unit": unit, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "units_reduced": units,
+                          "elapsed_max_s": el, "rank0_seeds": [seeds[0], seeds[-1]]}), flush=True)
+    if world > 1:
+        tdist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -651,11 +706,19 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / sharding / statistics reduction only, no GPU "
+                    "work (CPU test of the N > 1 plumbing; the line says dry_run)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher (nothing has touched the GPU yet)
+        raise SystemExit(self_launch(args.gpus))
     rank, world, local = egs_dist.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset "
+                         "WORLD_SIZE and let bench.py start its own ranks" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
     import torch.distributed as tdist
     dev = 0 if (world == 1 or args.share_device0) else local

@@ -34,6 +34,7 @@ EXPORTS = [
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
     "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig", "egs_box_lcp_murty",
+    "egs_box_lcp_batch", "egs_box_lcp_schur",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -195,11 +196,11 @@ class Context:
 
 
     def box_lcp_murty(self, A, b, lo, hi, max_iterations=0):
-        """lcp::SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442), n <= 96."""
+        """lcp::SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442), n <= 1024."""
         return self.box_lcp_dantzig(A, b, lo, hi, max_iterations, _entry="egs_box_lcp_murty")
 
     def box_lcp_dantzig(self, A, b, lo, hi, max_steps=0, _entry="egs_box_lcp_dantzig"):
-        """lcp::SolveLCP_BoxDantzig with the incremental factor (toolkit/lcp.cc:444-619), n <= 96.
+        """lcp::SolveLCP_BoxDantzig with the incremental factor (toolkit/lcp.cc:444-619), n <= 1024.
         Returns ok, x, w, A permuted in place (lower triangle), perm, pivot steps."""
         A = _f64(A).copy()
         b, lo, hi = map(_f64, (b, lo, hi))
@@ -210,6 +211,37 @@ class Context:
         if st not in (OK, ERR_LCP_FAILED):
             self.check(st)
         return bool(ok.value), x, w, A, perm, piv.value
+
+    def box_lcp_batch(self, algorithm, As, bs, los, his, max_steps=0, max_seconds=0.0):
+        """`len(As)` independent box LCPs in one launch (egs_box_lcp_batch); algorithm 0 = BoxMurty, 1 = BoxDantzig.
+        Returns lists ok, x, w, A (permuted in place), perm, pivots -- problem k's entries equal its single call's."""
+        ns = np.array([len(b) for b in bs], np.int32)
+        A = np.concatenate([_f64(a).reshape(-1) for a in As]).copy()
+        b, lo, hi = (np.concatenate([_f64(v) for v in vs]) for vs in (bs, los, his))
+        tot, cnt = int(ns.sum()), len(ns)
+        x = np.zeros(tot); w = np.zeros(tot); perm = np.zeros(tot, np.int32)
+        ok = np.zeros(cnt, np.int32); piv = np.zeros(cnt, np.int32)
+        self.check(load().egs_box_lcp_batch(self.h, C.c_int32(algorithm), C.c_int32(cnt), _p(ns), _p(A), _p(b), _p(lo), _p(hi),
+                                            C.c_int32(max_steps), C.c_double(max_seconds), _p(x), _p(w), _p(perm), _p(ok), _p(piv)))
+        vo = np.concatenate([[0], np.cumsum(ns)]); ao = np.concatenate([[0], np.cumsum(ns.astype(np.int64) ** 2)])
+        return ([bool(v) for v in ok], [x[vo[k]:vo[k + 1]] for k in range(cnt)], [w[vo[k]:vo[k + 1]] for k in range(cnt)],
+                [A[ao[k]:ao[k + 1]].reshape(ns[k], ns[k]) for k in range(cnt)], [perm[vo[k]:vo[k + 1]] for k in range(cnt)],
+                [int(v) for v in piv])
+
+    def box_lcp_schur(self, A, b, lo, hi, algorithm=0, nub=-1, reference_quirks=True, max_iterations=0, max_seconds=0.0):
+        """lcp::SolveLCP_BoxSchur (toolkit/lcp.cc:627-747).  Returns ok, x, w, A permuted in place (lower triangle),
+        perm of the partition, nub, inner pivots."""
+        A = _f64(A).copy()
+        b, lo, hi = map(_f64, (b, lo, hi))
+        n = b.shape[0]
+        x = np.zeros(n); w = np.zeros(n); perm = np.zeros(n, np.int32)
+        ok = C.c_int32(0); piv = C.c_int32(0); nub_out = C.c_int32(0)
+        st = load().egs_box_lcp_schur(self.h, C.c_int32(n), _p(A), _p(b), _p(lo), _p(hi), C.c_int32(algorithm), C.c_int32(nub),
+                                      C.c_int32(1 if reference_quirks else 0), C.c_int32(max_iterations), C.c_double(max_seconds),
+                                      _p(x), _p(w), _p(perm), C.byref(ok), C.byref(nub_out), C.byref(piv))
+        if st not in (OK, ERR_LCP_FAILED):
+            self.check(st)
+        return bool(ok.value), x, w, A, perm, nub_out.value, piv.value
 
 
 class Problem:

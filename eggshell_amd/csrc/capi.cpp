@@ -1560,13 +1560,13 @@ static egs_status box_lcp_incremental_entry(egs_context *ctx, int algorithm, int
                                      int32_t *pivots) {
   if (!ctx) return EGS_ERR_INVALID;
   if (ok) *ok = 0;
-  if (n < 1 || n > kDantzigMaxRows) return fail(ctx, EGS_ERR_INVALID, "incremental box LCP: 1 <= n <= 96");
+  if (n < 1 || n > kIncrementalMaxRows) return fail(ctx, EGS_ERR_INVALID, "incremental box LCP: 1 <= n <= 1024");
   if (!A || !b || !lo || !hi || !x || !w) return fail(ctx, EGS_ERR_INVALID, "NULL array");
   return guarded(ctx, [&]() -> egs_status {
     HIPCHK(hipSetDevice(ctx->device));
     int piv = 0;
     std::string msg;
-    const bool good = box_lcp_incremental(ctx->stream, algorithm, n, A, b, lo, hi, x, w, perm, max_steps, &piv, &msg);
+    const bool good = box_lcp_incremental(ctx->stream, algorithm, n, A, b, lo, hi, x, w, perm, max_steps, 0.0, &piv, &msg);
     if (ok) *ok = good ? 1 : 0;
     if (pivots) *pivots = piv;
     if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "the box LCP solver did not reach a solution" : msg);
@@ -1581,6 +1581,45 @@ egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const dou
 egs_status egs_box_lcp_murty(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo, const double *hi,
                              int32_t max_iterations, double *x, double *w, int32_t *perm, int32_t *ok, int32_t *iterations) {
   return box_lcp_incremental_entry(ctx, 0, n, A, b, lo, hi, max_iterations, x, w, perm, ok, iterations);
+}
+
+egs_status egs_box_lcp_batch(egs_context *ctx, int32_t algorithm, int32_t count, const int32_t *n, double *A, const double *b,
+                             const double *lo, const double *hi, int32_t max_steps, double max_seconds, double *x, double *w,
+                             int32_t *perm, int32_t *ok, int32_t *pivots) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (count < 0 || (count > 0 && (!n || !A || !b || !lo || !hi || !x || !w || !ok))) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  if (algorithm != 0 && algorithm != 1) return fail(ctx, EGS_ERR_INVALID, "algorithm: 0 (Murty) or 1 (Cottle-Dantzig)");
+  for (int k = 0; k < count; ++k) {
+    ok[k] = 0;
+    if (n[k] < 1 || n[k] > kIncrementalMaxRows) return fail(ctx, EGS_ERR_INVALID, "incremental box LCP: 1 <= n <= 1024");
+  }
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    box_lcp_incremental_batch(ctx->stream, algorithm, count, n, A, b, lo, hi, max_steps, max_seconds, x, w, perm, ok, pivots, nullptr);
+    return EGS_OK;     // per-problem outcome in ok[]
+  });
+}
+
+egs_status egs_box_lcp_schur(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo, const double *hi,
+                             int32_t algorithm, int32_t nub, int32_t reference_quirks, int32_t max_iterations, double max_seconds,
+                             double *x, double *w, int32_t *perm, int32_t *ok, int32_t *nub_out, int32_t *pivots) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (ok) *ok = 0;
+  if (n < 1 || nub > n) return fail(ctx, EGS_ERR_INVALID, "SolveLCP_BoxSchur: n >= 1, nub <= n");
+  if (!A || !b || !lo || !hi || !x || !w) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  if (algorithm != 0 && algorithm != 1) return fail(ctx, EGS_ERR_INVALID, "algorithm: 0 (Murty) or 1 (Cottle-Dantzig)");
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    int piv = 0, nub_found = 0;
+    std::string msg;
+    const bool good = box_lcp_schur(ctx->stream, n, A, b, lo, hi, algorithm, nub, reference_quirks != 0, max_iterations, max_seconds,
+                                    x, w, perm, &nub_found, &piv, &msg);
+    if (ok) *ok = good ? 1 : 0;
+    if (pivots) *pivots = piv;
+    if (nub_out) *nub_out = nub_found;
+    if (!good) return fail(ctx, EGS_ERR_LCP_FAILED, msg.empty() ? "SolveLCP_BoxSchur did not reach a solution" : msg);
+    return EGS_OK;
+  });
 }
 
 egs_status egs_update_contacts_joints(egs_context *ctx, int32_t n, const double *pos, const double *R,

@@ -30,14 +30,38 @@ bool dense_mixed_constraints_device(hipStream_t stream, int N, const double *dA,
 // a JacobiSVD (utils.cc:256-261).  *spd = false (and +inf) if the factorisation breaks down.
 double dense_condition_estimate(hipStream_t stream, int N, const double *dA, bool *spd);
 
-// lcp::SolveLCP_BoxDantzig with the incremental Cholesky factor of toolkit/lcp.cc (dantzig.hip): one wavefront,
-// everything in LDS, n <= kDantzigMaxRows.  A (host, row-major n x n; only the lower triangle is read) is permuted
-// in place as the reference leaves it (lower triangle written back); perm[k] = original index of final row k (may
-// be NULL).  Needs lo <= 0 <= hi, lo < hi (toolkit/lcp.cc:448-450).  max_steps > 0: give up after that many steps.
+// lcp::SolveLCP_BoxDantzig / SolveLCP_BoxMurty with the incremental Cholesky factor of toolkit/lcp.cc (dantzig.hip):
+// one workgroup per problem.  n <= kDantzigMaxRows: one wavefront, everything in LDS; up to kIncrementalMaxRows:
+// four wavefronts, the matrices in global memory.  A (host, row-major n x n; only the lower triangle is read) is
+// permuted in place as the reference leaves it (lower triangle written back); perm[k] = original index of final row
+// k (may be NULL).  Needs lo <= 0 <= hi (and lo < hi for Dantzig, toolkit/lcp.cc:448-450).
+// algorithm 1 = SolveLCP_BoxDantzig (:444-619), 0 = SolveLCP_BoxMurty on a LinearReducer (:213-328, 380-442; with
+// lo = 0, hi = +inf it is SolveLCP_Murty, :333-378).  max_steps > 0 = Settings::max_iterations, else 20 n + 1000;
+// max_seconds > 0 = Settings::max_time.
 constexpr int kDantzigMaxRows = 96;
-// algorithm 1 = SolveLCP_BoxDantzig, 0 = SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442; with
-// lo = 0, hi = +inf it is SolveLCP_Murty, :333-378); max_steps = Settings::max_iterations.
+constexpr int kIncrementalMaxRows = 1024;
 bool box_lcp_incremental(hipStream_t stream, int algorithm, int n, double *A, const double *b, const double *lo, const double *hi,
-                         double *x, double *w, int32_t *perm, int max_steps, int *pivots, std::string *msg);
+                         double *x, double *w, int32_t *perm, int max_steps, double max_seconds, int *pivots, std::string *msg);
+// `count` problems in one launch: problem k's matrix at A + sum_{j<k} n_j^2, its vectors at sum_{j<k} n_j.
+// ok / pivots / reason [count] (reason: 0 solved, 1 step limit, 2 non-positive pivot, 3 time limit; may be NULL).
+void box_lcp_incremental_batch(hipStream_t stream, int algorithm, int count, const int32_t *n, double *A, const double *b,
+                               const double *lo, const double *hi, int max_steps, double max_seconds, double *x, double *w,
+                               int32_t *perm, int32_t *ok, int32_t *pivots, int32_t *reason);
+// One problem that lives on the device (dA n x n contiguous, permuted in place; dx / dw out); h_lo / h_hi = host
+// copies of the bounds for the precondition check.
+bool box_lcp_incremental_device(hipStream_t stream, int algorithm, int n, double *dA, const double *db, const double *dlo,
+                                const double *dhi, const double *h_lo, const double *h_hi, int max_steps, double max_seconds,
+                                double *dx, double *dw, int *pivots, std::string *msg);
+
+// lcp::SolveLCP_BoxSchur (toolkit/lcp.cc:627-747): the two-pointer partition that brings the unbounded rows to the
+// front (A's lower triangle permuted in place, perm[k] = original index of row k, *nub_out = their number), Z = L L',
+// the Schur complement R = C - B Z^-1 B' and the reduced right-hand side on the blocked MFMA factorisation, the box
+// LCP on R by the incremental-factor solver above (algorithm 0 / 1; beyond kIncrementalMaxRows bounded rows by block
+// principal pivoting), then y = Z^-1 (c - B' z).  nub_arg >= 0 is the reference's test hook (:623-626), -1 scans the
+// bounds; q6 keeps the reference's literal classification test.  A: host, row-major, only the
+// lower triangle is read or written.
+bool box_lcp_schur(hipStream_t stream, int n, double *A, const double *b, const double *lo, const double *hi, int algorithm,
+                   int nub_arg, bool q6, int max_steps, double max_seconds, double *x, double *w, int32_t *perm, int *nub_out,
+                   int *pivots, std::string *msg);
 
 }  // namespace egs

@@ -341,17 +341,22 @@ __global__ void __launch_bounds__(256) symmetry_kernel(const double *A, int N, u
 
 // ---- gathers ---------------------------------------------------------------
 // Schur-stage trapezoid: rows = nepad + ni + 1, ld = nepad + ni (see header).
+// lower_only: A holds a symmetric matrix in its lower triangle and nothing else is read (toolkit/lcp.h:73).
 __global__ void build_schur_kernel(const double *A, const double *b, int N, const int *E, int ne, int nepad,
-                                   const int *I, int ni, double *T) {
+                                   const int *I, int ni, double *T, int lower_only) {
   const int ld = nepad + ni, rows = nepad + ni + 1;
   const size_t total = (size_t)rows * ld;
+  auto at = [&](int gr, int gcol) {
+    if (lower_only && gcol > gr) { const int t = gr; gr = gcol; gcol = t; }
+    return A[(size_t)gr * N + gcol];
+  };
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / ld), c = (int)(idx % ld);
     double v = 0.0;
     const int gc = c < ne ? E[c] : (c >= nepad ? I[c - nepad] : -1);
-    if (r < ne) { if (gc >= 0 && c < ne) v = A[(size_t)E[r] * N + gc]; }
+    if (r < ne) { if (gc >= 0 && c < ne) v = at(E[r], gc); }
     else if (r < nepad) v = (c == r) ? 1.0 : 0.0;
-    else if (r < nepad + ni) { if (gc >= 0) v = A[(size_t)I[r - nepad] * N + gc]; }
+    else if (r < nepad + ni) { if (gc >= 0) v = at(I[r - nepad], gc); }
     else { if (gc >= 0) v = b[gc]; }
     T[idx] = v;
   }
@@ -989,7 +994,7 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
     if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
   }
   // Schur stage: factor the E columns of [A_ee A_ei; A_ie A_ii; b^T]   (lcp.cc:286-294)
-  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE.p, ne, nepad, dI.p, ni, T.p);
+  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE.p, ne, nepad, dI.p, ni, T.p, 0);
   factor(s, T.p, ld, rows, nepad, fail_d.p, dinv.p);
   if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
   int fail = 0;
@@ -1023,6 +1028,130 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
   if (w) for (int i = 0; i < N; ++i) w[i] = 0.0;  // lcp.cc:332-333
   if (x) for (int k = 0; k < ne; ++k) x[E[k]] = xeh[k];
   for (int k = 0; k < ni; ++k) { if (x) x[I[k]] = xih[k]; if (w) w[I[k]] = wih[k]; }
+  return true;
+}
+
+
+// ---- lcp::SolveLCP_BoxSchur (toolkit/lcp.cc:627-747) -------------------------------------------------
+namespace {
+// A(i <-> j) on the lower triangle only (toolkit/lcp.cc:171-195), host side
+void swap_rows_and_columns_lower(double *A, int n, int i, int j) {
+  if (i == j) return;
+  if (i > j) std::swap(i, j);
+  for (int c = 0; c < i; ++c) std::swap(A[(size_t)i * n + c], A[(size_t)j * n + c]);
+  for (int r = j + 1; r < n; ++r) std::swap(A[(size_t)r * n + i], A[(size_t)r * n + j]);
+  for (int k = i + 1; k < j; ++k) std::swap(A[(size_t)k * n + i], A[(size_t)j * n + k]);
+  std::swap(A[(size_t)i * n + i], A[(size_t)j * n + j]);
+}
+__global__ void symmetrize_lower_kernel(double *A, int n) {    // A(r, c) = A(c, r) for c > r
+  const size_t total = (size_t)n * n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / n), c = (int)(idx % n);
+    if (c > r) A[idx] = A[(size_t)c * n + r];
+  }
+}
+}  // namespace
+
+bool box_lcp_schur(hipStream_t s, int n, double *A, const double *b_arg, const double *lo_arg, const double *hi_arg, int algorithm,
+                   int nub_arg, bool q6, int max_steps, double max_seconds, double *x, double *w, int32_t *perm_out, int *nub_out,
+                   int *pivots, std::string *msg) {
+  if (pivots) *pivots = 0;
+  if (n <= 0) throw std::invalid_argument("SolveLCP_BoxSchur: n >= 1");
+  if (nub_arg > n) throw std::invalid_argument("SolveLCP_BoxSchur: nub <= n");
+  const double big = std::numeric_limits<double>::max();
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<double> b(b_arg, b_arg + n), lo(lo_arg, lo_arg + n), hi(hi_arg, hi_arg + n);
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  // the partition of toolkit/lcp.cc:652-683: the unbounded indexes first, A's lower triangle swapped along
+  int nub = nub_arg;
+  std::vector<std::pair<int, int>> swaps;
+  if (nub < 0) {
+    nub = 0;
+    int nb = n - 1;
+    while (true) {
+      for (; nub <= nb; ++nub) if (q6 ? (lo[nub] > -big || hi[nub] < -big) : (lo[nub] > -big || hi[nub] < big)) break;
+      for (; nb >= nub; --nb) if (q6 ? (lo[nb] <= -big && hi[nb] >= -big) : (lo[nb] <= -big && hi[nb] >= big)) break;
+      if (nub > nb) break;
+      swaps.emplace_back(nub, nb);
+      std::swap(perm[nub], perm[nb]); std::swap(b[nub], b[nb]); std::swap(lo[nub], lo[nb]); std::swap(hi[nub], hi[nb]);
+    }
+  }
+  if (nub_out) *nub_out = nub;
+  if (perm_out) for (int k = 0; k < n; ++k) perm_out[k] = perm[k];
+  const int ne = nub, ni = n - nub;
+  // "infinity" is DBL_MAX or the real one (toolkit/lcp.h:149-150): the inner solvers see the real one
+  std::vector<double> l2(ni), h2(ni);
+  for (int k = 0; k < ni; ++k) { l2[k] = lo[nub + k] <= -big ? -inf : lo[nub + k]; h2[k] = hi[nub + k] >= big ? inf : hi[nub + k]; }
+
+  Buf<double> dA((size_t)n * n), db(n);
+  if (ne == 0) {
+    // entirely an LCP (toolkit/lcp.cc:695-700): the inner solver works on A itself and leaves its pivoting order there
+    if (n <= kIncrementalMaxRows) {
+      int piv = 0;
+      const bool good = box_lcp_incremental(s, algorithm, n, A, b.data(), l2.data(), h2.data(), x, w, nullptr, max_steps, max_seconds, &piv, msg);
+      if (pivots) *pivots = piv;
+      return good;
+    }
+    // beyond the incremental solver's reach: block principal pivoting on the symmetric matrix (same solution for SPD A;
+    // A is left as it was, NOT in the reference's pivoting order)
+    HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(db.p, b.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(symmetrize_lower_kernel, dim3(grid1((size_t)n * n)), dim3(256), 0, s, dA.p, n);
+    Buf<double> dx(n), dw(n);
+    int piv = 0;
+    const bool good = murty_device(s, n, dA.p, db.p, l2, h2, true, true, max_steps, max_seconds, dx.p, dw.p, &piv, msg);
+    if (pivots) *pivots = piv;
+    if (!good) return false;
+    HIPCHK(hipMemcpyAsync(x, dx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(w, dw.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return true;
+  }
+  // Schur stage on the caller's matrix (lower triangle) read through the permutation: E = perm[0, nub), I = the rest
+  HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(db.p, b_arg, n * sizeof(double), hipMemcpyHostToDevice, s));
+  const int nepad = (ne + NB - 1) / NB * NB;
+  const int ld = nepad + ni, rows = nepad + ni + 1;
+  Buf<double> T((size_t)rows * ld), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad), dinv((size_t)nepad * NB), dl2(ni), dh2(ni);
+  Buf<int> dE(ne), dI(ni), fail_d(1);
+  HIPCHK(hipMemcpyAsync(dE.p, perm.data(), ne * sizeof(int), hipMemcpyHostToDevice, s));
+  if (ni) HIPCHK(hipMemcpyAsync(dI.p, perm.data() + ne, ni * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, n, dE.p, ne, nepad, dI.p, ni, T.p, 1);
+  factor(s, T.p, ld, rows, nepad, fail_d.p, dinv.p);            // L L' = Z, Q = L^-1 B', R = C - Q'Q, rhs = d - B Z^-1 c
+  if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
+  // meanwhile the host applies the partition to the caller's lower triangle, as the reference leaves it
+  for (const auto &sw : swaps) swap_rows_and_columns_lower(A, n, sw.first, sw.second);
+  int fail = 0;
+  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (fail) { if (msg) *msg = "the unbounded block Z is not positive definite"; return false; }
+  if (ni) {
+    int piv = 0;
+    bool good;
+    if (ni <= kIncrementalMaxRows) {
+      HIPCHK(hipMemcpyAsync(dl2.p, l2.data(), ni * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(dh2.p, h2.data(), ni * sizeof(double), hipMemcpyHostToDevice, s));
+      good = box_lcp_incremental_device(s, algorithm, ni, lhs.p, rhs.p, dl2.p, dh2.p, l2.data(), h2.data(), max_steps, max_seconds, xi.p, wi.p, &piv, msg);
+    } else {
+      good = murty_device(s, ni, lhs.p, rhs.p, l2, h2, true, true, max_steps, max_seconds, xi.p, wi.p, &piv, msg);
+    }
+    if (pivots) *pivots = piv;
+    if (!good) return false;
+  }
+  // y = Z^-1 (c - B' z) = L^-T (L^-1 c - Q z)
+  std::vector<double> xih(ni), wih(ni), xeh(ne);
+  hipLaunchKernelGGL(xe_rhs_kernel, dim3(nepad / NB), dim3(1024), 0, s, T.p, nepad, ni, xi.p);
+  hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p, dinv.p);
+  HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (ni) {
+    HIPCHK(hipMemcpyAsync(xih.data(), xi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(wih.data(), wi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  for (int k = 0; k < ne; ++k) { x[perm[k]] = xeh[k]; w[perm[k]] = 0.0; }          // Unpermute (:741-744)
+  for (int k = 0; k < ni; ++k) { x[perm[ne + k]] = xih[k]; w[perm[ne + k]] = wih[k]; }
   return true;
 }
 

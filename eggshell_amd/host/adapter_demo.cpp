@@ -254,6 +254,40 @@ static void round2() {
     MatrixXd Ab2 = Ab;
     ok = lcp::SolveLCP(big, Ab2, bb, lb, hb, &x, &w);
     std::printf("lcp_capped_ok %d %d\n", ok ? 1 : 0, lcp::LastSolvePivots());
+    // The reference's own test shape (toolkit/lcp.cc:1105-1123, 1146-1199): ONLY THE LOWER TRIANGLE is handed over
+    // (here the upper one holds a sentinel that must neither be read nor written), default Settings, n = 20 as the
+    // reference's test and n = 300; every other row bounded, and Cottle-Dantzig as the inner algorithm on a third run.
+    for (int pass = 0; pass < 3; ++pass) {
+      const int m = pass == 1 ? 300 : 20;
+      MatrixXd Mm(m, m), Am(m, m);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) Mm(i, j) = ((i * 31 + j * 17 + (i * j) % 11) % 23 - 11) / 11.0;
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+          if (j > i) { Am(i, j) = 555.0; continue; }
+          double sacc = (i == j) ? 0.25 : 0.0;
+          for (int k = 0; k < m; ++k) sacc += Mm(k, i) * Mm(k, j);
+          Am(i, j) = sacc;
+        }
+      VectorXd bm(m), lm(m), hm(m);
+      for (int i = 0; i < m; ++i) {
+        bm(i) = ((i * 13) % 11 - 5) * 0.3;
+        const bool bounded = (i % 2 == 1) || (i % 7 == 0);
+        lm(i) = bounded ? -0.05 * (1 + i % 3) : -__DBL_MAX__;
+        hm(i) = bounded ? 0.04 * (1 + i % 4) : __DBL_MAX__;
+      }
+      lcp::Settings sl;
+      if (pass == 2) sl.algorithm = lcp::COTTLE_DANTZIG;
+      ok = lcp::SolveLCP(sl, Am, bm, lm, hm, &x, &w);
+      char name[64];
+      std::snprintf(name, sizeof name, "lcp_lower%d_ok", pass);
+      std::printf("%s %d %d\n", name, ok ? 1 : 0, lcp::LastSolvePivots());
+      std::snprintf(name, sizeof name, "lcp_lower%d_x", pass); print_vec(name, x);
+      std::snprintf(name, sizeof name, "lcp_lower%d_w", pass); print_vec(name, w);
+      VectorXd Av(m * m);
+      for (int i = 0; i < m * m; ++i) Av(i) = Am.data()[i];
+      std::snprintf(name, sizeof name, "lcp_lower%d_A", pass); print_vec(name, Av);
+    }
   }
 }
 

@@ -184,22 +184,27 @@ bool MixedConstraintsSolver(const MatrixXd &A, const VectorXd &b, const ArrayXb 
 // A x = b + w with lo <= 0 <= hi.  What is kept of the contract:
 //   * the dispatch of toolkit/lcp.cc:752-785, including its two refusals (Schur complement
 //     or Cottle-Dantzig without box_lcp: the reference Panics, here egs::Error / EGS_ERR_INVALID);
-//   * schur_complement: unbounded rows (lo = -inf or -DBL_MAX and hi = +inf or DBL_MAX) are
-//     eliminated first (SolveLCP_BoxSchur, toolkit/lcp.cc:627-747) and A IS PERMUTED IN PLACE
-//     exactly as BoxSchur's two-pointer partition leaves it (unbounded rows first);
+//   * only the LOWER TRIANGLE of A is ever read or written (toolkit/lcp.h:73; the reference's tests hand
+//     over lower triangles, toolkit/lcp.cc:808, 880-881, 913, 957, 1109-1110);
+//   * schur_complement (the default): SolveLCP_BoxSchur (toolkit/lcp.cc:627-747) on the device
+//     (egs_box_lcp_schur): unbounded rows (lo = -inf or -DBL_MAX and hi = +inf or DBL_MAX) come first by
+//     its two-pointer partition, Z = L L', R = C - B Z^-1 B', the box LCP on R by SolveLCP_BoxMurty /
+//     SolveLCP_BoxDantzig (Settings::algorithm), back-substitution; A IS PERMUTED IN PLACE as the reference
+//     leaves it (the partition; plus the inner solver's pivoting order when no row is unbounded, :695-700);
 //     quirk Q6 (toolkit/lcp.cc:664, 669 test `hi < -DBL_MAX`, so a row with lo = -inf and a
 //     FINITE hi is classed unbounded) is reproduced when reference_quirks is set;
-//   * max_iterations and max_time: the solve gives up and returns false (toolkit/lcp.h:161-167);
+//   * max_iterations and max_time: the solve gives up and returns false (toolkit/lcp.h:161-167); the device
+//     loops also carry a cap of their own (20 n + 1000 steps) where the reference would loop for ever;
 //   * box_lcp = false: lo = 0, hi = +inf whatever the vectors hold (toolkit/lcp.h:152-154).
-//   * schur_complement = false (toolkit/lcp.cc:768-781): up to 96 rows, algorithm = COTTLE_DANTZIG runs
-//     SolveLCP_BoxDantzig and algorithm = MURTY runs SolveLCP_BoxMurty / SolveLCP_Murty on a LinearReducer
-//     themselves on the device (egs_box_lcp_dantzig / egs_box_lcp_murty: the incremental Cholesky factor
-//     of AddCholeskyRow / SwapCholeskyRows, toolkit/lcp.cc:91-157), and A's lower triangle is permuted in
-//     place by their pivoting order, as in the reference.
-// What differs, by design: the Schur-reduced problem and problems beyond 96 rows go
-// through block principal pivoting with a single-index safeguard (fresh blocked factorisations on the
-// matrix cores; same unique solution), so there A is left in BoxSchur's order or untouched instead of
-// carrying the pivoting order of the inner solver.
+//   * schur_complement = false (toolkit/lcp.cc:768-781): algorithm = COTTLE_DANTZIG runs SolveLCP_BoxDantzig
+//     and algorithm = MURTY runs SolveLCP_BoxMurty / SolveLCP_Murty on a LinearReducer themselves on the
+//     device (egs_box_lcp_batch: the incremental Cholesky factor of AddCholeskyRow / SwapCholeskyRows,
+//     toolkit/lcp.cc:91-157), and A's lower triangle is permuted in place by their pivoting order, as in
+//     the reference.
+// What differs, by design: a bounded part beyond 1024 rows goes through block principal
+// pivoting with a single-index safeguard (fresh blocked factorisations on the matrix cores; same unique
+// solution), so there A is left in BoxSchur's order or untouched instead of carrying the pivoting order of
+// the inner solver.
 namespace lcp {
 enum Algorithm { MURTY, COTTLE_DANTZIG };
 struct Settings {

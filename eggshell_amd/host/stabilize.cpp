@@ -119,70 +119,51 @@ bool lcp::SolveLCP(const Settings &settings, MatrixXd &A, const VectorXd &b, con
     throw egs::Error(EGS_ERR_INVALID, "Cottle Dantzig solver only available for box LCP");
   if (settings.algorithm != MURTY && settings.algorithm != COTTLE_DANTZIG) throw egs::Error(EGS_ERR_INVALID, "Unknown LCP solver selection");
   const double inf = std::numeric_limits<double>::infinity();
-  VectorXd l(N), h(N);
-  ArrayXb C(N);
-  std::vector<char> unbounded(N, 0);
-  for (int i = 0; i < N; ++i) {
-    l(i) = settings.box_lcp ? lo(i) : 0.0;    // toolkit/lcp.h:152-154
-    h(i) = settings.box_lcp ? hi(i) : inf;
-    // "infinity" is DBL_MAX or the real infinity (toolkit/lcp.h:149-150).  A row is unbounded when both
-    // bounds are infinite; the reference tests `hi < -DBL_MAX` (quirk Q6, toolkit/lcp.cc:664, 669), i.e.
-    // the lower bound alone decides.
-    const bool lo_inf = l(i) <= -__DBL_MAX__, hi_inf = h(i) >= __DBL_MAX__;
-    unbounded[i] = settings.schur_complement && (settings.reference_quirks ? lo_inf : (lo_inf && hi_inf));
-    if (lo_inf) l(i) = -inf;
-    if (hi_inf || (unbounded[i] && settings.reference_quirks)) h(i) = inf;   // Q6: the finite hi of such a row is never looked at
-    C(i) = unbounded[i] ? 1 : 0;
-  }
+  const int max_it = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
+  const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
+  const int algorithm = settings.algorithm == COTTLE_DANTZIG ? 1 : 0;
+  x->resize(N); w->resize(N);
+  int32_t ok = 0, pivots = 0;
   if (settings.schur_complement) {
-    // SolveLCP_BoxSchur permutes the problem so that the unbounded rows come first, and A stays permuted
-    // (toolkit/lcp.h:170-171, toolkit/lcp.cc:656-683): the same two-pointer partition, applied to A's rows
-    // and columns.  The solve below works on the unpermuted copy; x and w come back in the caller's order,
-    // as BoxSchur's Unpermute leaves them.
-    std::vector<char> ub = unbounded;
-    const MatrixXd A0 = A;
-    std::vector<int> perm(N);
-    for (int i = 0; i < N; ++i) perm[i] = i;
-    int nub = 0, nb = N - 1;
-    while (true) {
-      for (; nub <= nb; ++nub) if (!ub[nub]) break;
-      for (; nb >= nub; --nb) if (ub[nb]) break;
-      if (nub > nb) break;
-      std::swap(ub[nub], ub[nb]);
-      std::swap(perm[nub], perm[nb]);
-    }
-    for (int r = 0; r < N; ++r)
-      for (int c = 0; c < N; ++c) A(r, c) = A0(perm[r], perm[c]);
-    x->resize(N); w->resize(N);
-    int32_t ok = 0, pivots = 0;
-    const int max_piv = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
-    const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
-    egs_status st = egs_mixed_constraints_solve_limits(egs::DefaultContext(), N, A0.data(), b.data(), C.data(), l.data(), h.data(),
-                                                       /*bounds + block pivoting*/ 3, max_piv, max_sec, x->data(), w->data(), &ok, &pivots);
+    // SolveLCP_BoxSchur (toolkit/lcp.cc:627-747) on the device.  Like the reference it reads and writes ONLY the lower
+    // triangle of A (toolkit/lcp.h:73; the reference's own test hands over a lower triangle, toolkit/lcp.cc:1109-1110) and
+    // leaves A permuted: unbounded rows first, and the inner solver's pivoting order when nothing is unbounded.
+    int32_t nub = 0;
+    egs_status st = egs_box_lcp_schur(egs::DefaultContext(), N, A.data(), b.data(), lo.data(), hi.data(), algorithm, /*nub: scan*/ -1,
+                                      settings.reference_quirks ? 1 : 0, max_it, max_sec, x->data(), w->data(), nullptr, &ok, &nub, &pivots);
     g_last_lcp_pivots = pivots;
     if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
     return ok != 0;
   }
-  x->resize(N); w->resize(N);
-  int32_t ok = 0, pivots = 0;
-  const int max_piv = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
-  const double max_sec = settings.max_time >= __DBL_MAX__ ? 0.0 : settings.max_time;
-  if (N <= 96) {
+  VectorXd l(N), h(N);
+  for (int i = 0; i < N; ++i) {
+    l(i) = settings.box_lcp ? lo(i) : 0.0;    // toolkit/lcp.h:152-154
+    h(i) = settings.box_lcp ? hi(i) : inf;
+    // "infinity" is DBL_MAX or the real infinity (toolkit/lcp.h:149-150)
+    if (l(i) <= -__DBL_MAX__) l(i) = -inf;
+    if (h(i) >= __DBL_MAX__) h(i) = inf;
+  }
+  if (N <= 1024) {
     // Without the Schur complement the reference runs SolveLCP_BoxDantzig (toolkit/lcp.cc:444-619) or
     // SolveLCP_BoxMurty / SolveLCP_Murty on a LinearReducer (:213-442): both on the device with their
     // incremental Cholesky factor; A's lower triangle carries the pivoting order afterwards, as in the
     // reference.  Their preconditions (lo <= 0 <= hi; lo < hi for Dantzig, :448-450) come back as
-    // EGS_ERR_INVALID, the iteration limit as false.
-    const int lim = settings.max_iterations >= __INT_MAX__ ? 0 : std::max(settings.max_iterations, 1);
-    egs_status st = settings.algorithm == COTTLE_DANTZIG
-        ? egs_box_lcp_dantzig(egs::DefaultContext(), N, A.data(), b.data(), l.data(), h.data(), 0, x->data(), w->data(), nullptr, &ok, &pivots)
-        : egs_box_lcp_murty(egs::DefaultContext(), N, A.data(), b.data(), l.data(), h.data(), lim, x->data(), w->data(), nullptr, &ok, &pivots);
+    // EGS_ERR_INVALID, the iteration / time limit as false.
+    const int32_t n32 = N;
+    egs_status st = egs_box_lcp_batch(egs::DefaultContext(), algorithm, 1, &n32, A.data(), b.data(), l.data(), h.data(), max_it, max_sec,
+                                      x->data(), w->data(), nullptr, &ok, &pivots);
     g_last_lcp_pivots = pivots;
-    if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
+    if (st != EGS_OK) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
     return ok != 0;
   }
-  egs_status st = egs_mixed_constraints_solve_limits(egs::DefaultContext(), N, A.data(), b.data(), C.data(), l.data(), h.data(),
-                                                     /*bounds + block pivoting*/ 3, max_piv, max_sec, x->data(), w->data(), &ok, &pivots);
+  // beyond the incremental solvers: block principal pivoting on the symmetric matrix the lower triangle stands for
+  // (same solution for SPD A; A keeps its order)
+  MatrixXd Asym(N, N);
+  ArrayXb C(N);
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c <= r; ++c) { Asym(r, c) = A(r, c); Asym(c, r) = A(r, c); }
+  egs_status st = egs_mixed_constraints_solve_limits(egs::DefaultContext(), N, Asym.data(), b.data(), C.data(), l.data(), h.data(),
+                                                     /*bounds + block pivoting*/ 3, max_it, max_sec, x->data(), w->data(), &ok, &pivots);
   g_last_lcp_pivots = pivots;
   if (st != EGS_OK && st != EGS_ERR_LCP_FAILED) throw egs::Error(st, egs_last_error(egs::DefaultContext()));
   return ok != 0;

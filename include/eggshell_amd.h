@@ -342,9 +342,10 @@ egs_status egs_world_info(egs_world *w, int32_t *n_constraints, int32_t *n_conta
  * pivot).  A [n][n] row-major: only the lower triangle is read, and it is PERMUTED IN PLACE exactly as the
  * reference leaves it (toolkit/lcp.h:170-171); perm[k] = original index of the final row k (may be NULL).
  * Requires lo <= 0 <= hi and lo < hi (toolkit/lcp.cc:448-450: EGS_ERR_INVALID otherwise) and
- * 1 <= n <= 96 (one wavefront, both matrices in LDS; larger problems: egs_mixed_constraints_solve with
- * use_bounds = 3 reaches the same solution with blocked factorisations).  max_steps > 0 gives up after that
- * many pivot steps (*ok = 0, EGS_ERR_LCP_FAILED), as does a non-positive pivot (A not positive definite).  */
+ * 1 <= n <= 1024 (n <= 96: one wavefront, both matrices in LDS; above: four wavefronts, A permuted in place
+ * in device memory).  max_steps > 0 gives up after that many pivot steps, 0 = the library's cap of
+ * 20 n + 1000 (*ok = 0, EGS_ERR_LCP_FAILED) -- the device loop always has an exit, where the reference's
+ * has none (toolkit/lcp.cc:493) -- as does a non-positive pivot (A not positive definite).                  */
 egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo,
                                const double *hi, int32_t max_steps, double *x, double *w, int32_t *perm,
                                int32_t *ok, int32_t *pivots);
@@ -352,12 +353,43 @@ egs_status egs_box_lcp_dantzig(egs_context *ctx, int32_t n, double *A, const dou
 /* Replaces lcp::SolveLCP_BoxMurty (toolkit/lcp.cc:380-442; with lo = 0, hi = +inf / DBL_MAX it is
  * SolveLCP_Murty, :333-378) on its LinearReducer (:213-328): principal pivoting that moves the first
  * violated index (in the caller's order) in or out of the index set and keeps the set's Cholesky factor
- * up to date row by row.  Same arguments, limits (n <= 96, lo <= 0 <= hi) and in-place permutation of A's
+ * up to date row by row.  Same arguments, limits (n <= 1024, lo <= 0 <= hi) and in-place permutation of A's
  * lower triangle as egs_box_lcp_dantzig; max_iterations > 0 = Settings::max_iterations (the call then
  * reports *ok = 0, EGS_ERR_LCP_FAILED, as the reference returns false, toolkit/lcp.cc:438-441).       */
 egs_status egs_box_lcp_murty(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo,
                              const double *hi, int32_t max_iterations, double *x, double *w, int32_t *perm,
                              int32_t *ok, int32_t *iterations);
+
+/* The same two solvers (algorithm 0 = SolveLCP_BoxMurty, 1 = SolveLCP_BoxDantzig) on `count` independent
+ * problems in ONE launch, a workgroup per problem -- what a batch of ensembles hands lcp::SolveLCP
+ * (toolkit/lcp.h:172-174), which the reference calls once per problem.  Problem k has n[k] rows; its matrix
+ * sits at A + sum_{j<k} n[j]^2 (row-major, lower triangle read and permuted in place), its vectors (b, lo, hi,
+ * x, w, perm) at sum_{j<k} n[j].  ok[k] / pivots[k]: the problem's own outcome and step count -- the same as
+ * its single call.  max_steps / max_seconds: Settings::max_iterations / max_time per problem (0 = the
+ * library's cap / none).  Returns EGS_OK when every problem was run (see ok[]); EGS_ERR_INVALID for a bad
+ * size or bounds that break lo <= 0 <= hi (lo < hi for Dantzig).  perm, pivots may be NULL.               */
+egs_status egs_box_lcp_batch(egs_context *ctx, int32_t algorithm, int32_t count, const int32_t *n, double *A,
+                             const double *b, const double *lo, const double *hi, int32_t max_steps,
+                             double max_seconds, double *x, double *w, int32_t *perm, int32_t *ok,
+                             int32_t *pivots);
+
+/* Replaces lcp::SolveLCP_BoxSchur (toolkit/lcp.cc:627-747), what lcp::SolveLCP (toolkit/lcp.h:172-174,
+ * toolkit/lcp.cc:752-785) runs under its default Settings (schur_complement = true, box_lcp = true):
+ * the two-pointer partition that brings the unbounded rows (lo = -infinity, hi = +infinity; "infinity" =
+ * DBL_MAX or the real one) to the front, Z = L L' on them, the Schur complement R = C - B Z^-1 B' and its
+ * right-hand side (:714-727), the box LCP on R by SolveLCP_BoxMurty (algorithm 0) or SolveLCP_BoxDantzig
+ * (1), and y = Z^-1 (c - B' z).  A: row-major n x n, ONLY THE LOWER TRIANGLE IS READ OR WRITTEN
+ * (toolkit/lcp.h:73); it is permuted in place as the reference leaves it: by the partition and, when no row
+ * is unbounded, by the inner solver's pivoting (:695-700).  perm[k] = original index of row k after the
+ * partition (may be NULL).  nub >= 0 is the reference's test hook (:623-626: that many leading indexes are
+ * taken as unbounded unseen), -1 scans the bounds; *nub_out = test_nub_from_SolveLCP_BoxSchur.
+ * reference_quirks != 0 keeps the literal tests `hi < -DBL_MAX` of :664, 669 (the lower
+ * bound alone decides); 0 tests hi against +DBL_MAX.  max_iterations / max_seconds as above.  Bounded parts
+ * beyond 1024 rows are solved by block principal pivoting (same solution).                                  */
+egs_status egs_box_lcp_schur(egs_context *ctx, int32_t n, double *A, const double *b, const double *lo,
+                             const double *hi, int32_t algorithm, int32_t nub, int32_t reference_quirks,
+                             int32_t max_iterations, double max_seconds, double *x, double *w, int32_t *perm,
+                             int32_t *ok, int32_t *nub_out, int32_t *pivots);
 
 /* ---- diagnostics (host only, needs no GPU) -------------------------------
  * The schedule the solver derives from the constraint graph: islands, the

@@ -176,6 +176,9 @@ int otk_box_dantzig(int n, double *A, const double *b, const double *lo, const d
                     double *x, double *w, int *perm_out, int *pivots);
 int otk_box_murty(int n, double *A, const double *b, const double *lo, const double *hi, int max_iterations,
                   double *x, double *w, int *perm_out, int *iters);
+/* SolveLCP_BoxSchur (toolkit/lcp.cc:627-747); nub_arg = -1 scans, >= 0 is the reference's test hook */
+int otk_box_schur(int n, double *A, const double *b, const double *lo, const double *hi, int algorithm,
+                  int max_iterations, int nub_arg, int q6, double *x, double *w, int *perm_out, int *nub_out, int *iters);
 
 int orc_collide_box_ground(const double c[3], const double R[9],
                            const double side[3], double *contacts);

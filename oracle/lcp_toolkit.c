@@ -346,3 +346,105 @@ int otk_box_murty(int n, double *A, const double *b, const double *lo, const dou
   free(buf); free(perm);
   return ok && solved;
 }
+
+/* SolveLCP_BoxSchur (toolkit/lcp.cc:627-747) and the dispatch of lcp::SolveLCP it recurses into (:752-785).
+ *   algorithm 0 = MURTY -> SolveLCP_BoxMurty on the bounded part, 1 = COTTLE_DANTZIG -> SolveLCP_BoxDantzig.
+ *   nub_arg >= 0 is the reference's test hook (:623-626): the first nub_arg indexes are taken as unbounded
+ *   without looking; -1 scans lo / hi with the two-pointer partition of :656-683.
+ *   q6 != 0 keeps the reference's classification tests literally (`hi < -DBL_MAX`, `hi >= -DBL_MAX`: the
+ *   lower bound alone decides); q6 == 0 tests hi against +DBL_MAX as was surely meant.
+ * A (row-major, lower triangle only) is permuted in place: the partition's swaps always, and the inner
+ * solver's pivoting order only when nub == 0 (otherwise the inner solver permutes the temporary R).
+ * perm_out[k] = original index of row k after the PARTITION (the inner permutation is not reported, as in the
+ * reference, whose `permutation` object only records the outer swaps).  *nub_out = test_nub_from_SolveLCP_BoxSchur.
+ * Returns 1 solved, 0 failed (inner solver gave up / a non-positive pivot), -1 allocation failure.
+ * Operation order of the dense steps (Cholesky of Z, Q = L^-1 B', R = C - Q'Q, the two solves) is the plain
+ * column-oriented one of this file, not Eigen's blocked kernels (unknown here): results agree to rounding. */
+int otk_box_schur(int n, double *A, const double *b_arg, const double *lo_arg, const double *hi_arg, int algorithm,
+                  int max_iterations, int nub_arg, int q6, double *x, double *w, int *perm_out, int *nub_out, int *iters) {
+  const double big = __DBL_MAX__;
+  double *vec = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+  int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  if (!vec || !perm) { free(vec); free(perm); return -1; }
+  double *b = vec, *lo = b + n, *hi = lo + n;
+  for (int i = 0; i < n; ++i) { b[i] = b_arg[i]; lo[i] = lo_arg[i]; hi[i] = hi_arg[i]; perm[i] = i; }
+  int nub = nub_arg, did_swaps = 0, ret = 1, it = 0;
+  if (nub < 0) {
+    nub = 0;
+    int nb = n - 1;
+    while (1) {
+      for (; nub <= nb; nub++) {          /* :660-663 */
+        const int bounded = q6 ? (lo[nub] > -big || hi[nub] < -big) : (lo[nub] > -big || hi[nub] < big);
+        if (bounded) break;
+      }
+      for (; nb >= nub; nb--) {           /* :665-669 */
+        const int unbounded = q6 ? (lo[nb] <= -big && hi[nb] >= -big) : (lo[nb] <= -big && hi[nb] >= big);
+        if (unbounded) break;
+      }
+      if (nub > nb) break;
+      otk_swap_rows_and_columns(A, n, nub, nb, perm);
+      swapd(b, nub, nb); swapd(lo, nub, nb); swapd(hi, nub, nb);
+      did_swaps = 1;
+    }
+  }
+  if (nub_out) *nub_out = nub;
+  if (perm_out) for (int k = 0; k < n; ++k) perm_out[k] = perm[k];
+  if (nub == n) {                          /* :687-692: x = A.llt().solve(b), w = 0 (not unpermuted: no swaps happened) */
+    double *L = (double *)calloc((size_t)n * n, sizeof(double));
+    if (!L) { free(vec); free(perm); return -1; }
+    for (int r = 0; r < n; ++r) for (int c = 0; c <= r; ++c) AT(L, r, c) = AT(A, r, c);
+    if (otk_cholesky(L, n)) ret = 0;
+    for (int i = 0; i < n; ++i) { x[i] = b[i]; w[i] = 0.0; }
+    if (ret) otk_lltsolve(L, n, n, x);
+    free(L);
+  } else if (nub == 0) {                   /* :695-700: entirely an LCP; did_swaps is false, A goes to the inner solver itself */
+    (void)did_swaps;
+    ret = algorithm == 1 ? otk_box_dantzig(n, A, b, lo, hi, x, w, NULL, &it)
+                         : otk_box_murty(n, A, b, lo, hi, max_iterations, x, w, NULL, &it);
+  } else {
+    const int nb2 = n - nub;
+    double *buf = (double *)calloc((size_t)nub * nub + (size_t)nub * nb2 + (size_t)nb2 * nb2 + 4 * (size_t)n, sizeof(double));
+    if (!buf) { free(vec); free(perm); return -1; }
+    double *L = buf, *Q = L + (size_t)nub * nub, *R = Q + (size_t)nub * nb2, *t = R + (size_t)nb2 * nb2, *rhs = t + n,
+           *z = rhs + n, *w2 = z + n;
+    /* Z = A[0:nub, 0:nub], B = A[nub:, 0:nub], C = A[nub:, nub:], lower triangles only (:704-712) */
+    for (int r = 0; r < nub; ++r) for (int c = 0; c <= r; ++c) L[(size_t)r * nub + c] = AT(A, r, c);
+    if (otk_cholesky(L, nub)) ret = 0;      /* L L' = Z */
+    if (ret) {
+      for (int j = 0; j < nb2; ++j) {       /* Q = L^-1 B', one column of B' (= row of B) at a time */
+        for (int k = 0; k < nub; ++k) t[k] = AT(A, nub + j, k);
+        otk_lsolve(L, nub, nub, t);
+        for (int k = 0; k < nub; ++k) Q[(size_t)k * nb2 + j] = t[k];
+      }
+      for (int i = 0; i < nb2; ++i)         /* R = C - Q'Q, lower triangle (:717-719) */
+        for (int j = 0; j <= i; ++j) {
+          double s = 0.0;
+          for (int k = 0; k < nub; ++k) s = s + Q[(size_t)k * nb2 + i] * Q[(size_t)k * nb2 + j];
+          R[(size_t)i * nb2 + j] = AT(A, nub + i, nub + j) - s;
+        }
+      for (int k = 0; k < nub; ++k) t[k] = b[k];
+      otk_lltsolve(L, nub, nub, t);         /* t = Z^-1 c */
+      for (int i = 0; i < nb2; ++i) {       /* rhs = d - B t */
+        double s = 0.0;
+        for (int k = 0; k < nub; ++k) s = s + AT(A, nub + i, k) * t[k];
+        rhs[i] = b[nub + i] - s;
+      }
+      ret = algorithm == 1 ? otk_box_dantzig(nb2, R, rhs, lo + nub, hi + nub, z, w2, NULL, &it)
+                           : otk_box_murty(nb2, R, rhs, lo + nub, hi + nub, max_iterations, z, w2, NULL, &it);
+      if (ret == 1) {
+        for (int k = 0; k < nub; ++k) {     /* y = Z^-1 (c - B' z) */
+          double s = 0.0;
+          for (int i = 0; i < nb2; ++i) s = s + AT(A, nub + i, k) * z[i];
+          t[k] = b[k] - s;
+        }
+        otk_lltsolve(L, nub, nub, t);
+        for (int k = 0; k < nub; ++k) { x[perm[k]] = t[k]; w[perm[k]] = 0.0; }
+        for (int i = 0; i < nb2; ++i) { x[perm[nub + i]] = z[i]; w[perm[nub + i]] = w2[i]; }
+      }
+    }
+    free(buf);
+  }
+  if (iters) *iters = it;
+  free(vec); free(perm);
+  return ret;
+}

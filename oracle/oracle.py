@@ -345,6 +345,18 @@ def tk_box_murty(A, b, lo, hi, max_iterations=2**31 - 1):
     return ok == 1, x, w, A, perm, it.value
 
 
+def tk_box_schur(A, b, lo, hi, algorithm=0, max_iterations=2**31 - 1, nub=-1, q6=True):
+    """SolveLCP_BoxSchur (toolkit/lcp.cc:627-747): returns ok, x, w, A permuted in place, perm of the partition,
+    nub (test_nub_from_SolveLCP_BoxSchur), inner iterations."""
+    A = _f64(A).copy()
+    b, lo, hi = _f64(b), _f64(lo), _f64(hi)
+    n = b.shape[0]
+    x = np.zeros(n); w = np.zeros(n); perm = np.zeros(n, np.int32); it = C.c_int(0); nub_out = C.c_int(0)
+    ok = lib().otk_box_schur(C.c_int(n), _p(A), _p(b), _p(lo), _p(hi), C.c_int(algorithm), C.c_int(max_iterations),
+                             C.c_int(nub), C.c_int(1 if q6 else 0), _p(x), _p(w), _p(perm), C.byref(nub_out), C.byref(it))
+    return ok == 1, x, w, A, perm, nub_out.value, it.value
+
+
 # ---- collision ------------------------------------------------------------
 def collide_box_ground(c, R, side=(0.3, 0.3, 0.3)):
     c, R, side = _f64(c), _f64(R), _f64(side)

@@ -66,3 +66,48 @@ def test_two_rank_stats_reduction_gloo():
         assert units == 1024 * 3                    # SUM of per-rank units = 1024 ensembles x steps
         assert citers == 1024 * 256.0 * 50
         assert abs(resid - 0.2) < 1e-15 and failed is False
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts two ranks itself (gloo here, no GPU:
+    --dry-run stops before the first GPU call), rank 0 prints ONE line, and the reduction saw both shards."""
+    pytest.importorskip("torch")
+    r, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo", "--legs", "none",
+                           "--workload", "c4", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["units_reduced"] == 1024 * 3             # SUM over both ranks: every ensemble exactly once
+    assert out["elapsed_max_s"] == 1.25                 # MAX over ranks
+    assert out["rank0_seeds"] == [0, 511]
+    # the default (C3, weak scaling): every rank its own --batch piles
+    r, lines = _run_bench(["--gpus", "2", "--steps", "2", "--dist-backend", "gloo", "--legs", "none", "--batch", "5", "--dry-run"])
+    assert r.returncode == 0 and len(lines) == 1 and lines[0]["units_reduced"] == 2 * 5 * 2 and lines[0]["scaling"] == "weak"
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies takes the job down with a non-zero exit code (here: no GPU and no --dry-run, so every rank
+    fails at Context creation -- the product path never falls back to the CPU)."""
+    pytest.importorskip("torch")
+    r, lines = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-backend", "gloo", "--legs", "none", "--cpu-seconds", "0"])
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the ranks would run")
+    assert r.returncode != 0 and not lines
+
+
+def test_bench_under_a_launcher_checks_the_world_size():
+    r, lines = _run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -179,8 +179,11 @@ def test_solvelcp_contract(out):
     assert out["lcp_default_x"][5] <= 0.5
     # A was permuted in place as BoxSchur's partition does: swap(0, 8), swap(1, 3) -> unbounded rows first
     perm = list(range(n)); perm[0], perm[8] = perm[8], perm[0]; perm[1], perm[3] = perm[3], perm[1]
-    assert np.abs(out["lcp_default_A"].reshape(n, n) - A[np.ix_(perm, perm)]).max() < 1e-12
-    assert np.abs(out["lcp_default_A"].reshape(n, n) - A).max() > 0.1        # ... and that is not the caller's order
+    # (the lower triangle only: toolkit/lcp.cc:171-195 never touches the upper one)
+    Ad = out["lcp_default_A"].reshape(n, n)
+    assert np.abs(np.tril(Ad) - np.tril(A[np.ix_(perm, perm)])).max() < 1e-12
+    assert np.abs(np.triu(Ad, 1) - np.triu(A, 1)).max() < 1e-12
+    assert np.abs(np.tril(Ad) - np.tril(A)).max() > 0.1                      # ... and that is not the caller's order
     # quirk Q6 reproduced on request: row 5 (lo = -inf, hi finite) is classed unbounded, its hi never looked at
     assert int(out["lcp_q6_ok"][0]) == 1
     unb6 = unb.copy(); unb6[5] = True
@@ -211,3 +214,24 @@ def test_solvelcp_contract(out):
     assert ok == 1 and piv > 1
     okc, pivc = out["lcp_capped_ok"].astype(int)
     assert okc == 0 and pivc <= 1                                  # max_iterations = 1: gives up, returns false
+    # the reference's own test shape: a lower triangle with a sentinel above it, default Settings (SolveLCP_BoxSchur);
+    # x, w and the permuted matrix against the oracle's restatement of toolkit/lcp.cc:627-747
+    for pas, m in ((0, 20), (1, 300), (2, 20)):
+        i, j = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+        Mm = ((i * 31 + j * 17 + (i * j) % 11) % 23 - 11) / 11.0
+        Af = Mm.T @ Mm + 0.25 * np.eye(m)
+        k = np.arange(m)
+        bm = ((k * 13) % 11 - 5) * 0.3
+        bounded = (k % 2 == 1) | (k % 7 == 0)
+        big = np.finfo(np.float64).max
+        lm = np.where(bounded, -0.05 * (1 + k % 3), -big); hm = np.where(bounded, 0.04 * (1 + k % 4), big)
+        okl, pivl = out["lcp_lower%d_ok" % pas].astype(int)
+        xl, wl, Al = out["lcp_lower%d_x" % pas], out["lcp_lower%d_w" % pas], out["lcp_lower%d_A" % pas].reshape(m, m)
+        oko, xo, wo, Ao, permo, nubo, ito = orc.tk_box_schur(np.tril(Af), bm, lm, hm, algorithm=1 if pas == 2 else 0, q6=False)
+        assert okl == 1 and oko and nubo == m - bounded.sum()
+        assert np.abs(xl - xo).max() < 1e-9 and np.abs(wl - wo).max() < 1e-9
+        assert np.linalg.norm(Af @ xl - bm - wl) < 1e-6 and (xl >= lm).all() and (xl <= hm).all()      # toolkit/lcp.cc:1168-1172
+        assert np.all(wl[~bounded] == 0)
+        assert np.all(Al[np.triu_indices(m, 1)] == 555.0)          # the upper triangle was neither read nor written
+        assert np.abs(np.tril(Al) - np.tril(Ao)).max() < 1e-11     # (demo and numpy build A in different summation orders)
+        assert np.abs(np.tril(Al) - np.tril(Af[np.ix_(permo, permo)])).max() < 1e-11

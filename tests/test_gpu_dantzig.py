@@ -3,7 +3,8 @@
 (oracle/lcp_toolkit.c, pinned by the reference's own property tests in tests/test_oracle_lcp_toolkit.py):
 the reference's Dantzig property test restated (N = 7, 6 bound variants, box-LCP conditions, |Ax - b - w| <
 1e-6), the same pivot sequence and the same in-place permutation of A as the sequential algorithm, sizes up
-to the 96-row limit, and the documented refusals."""
+to the 96-row limit of the in-LDS instantiation and beyond it (matrices in device memory, four wavefronts), the
+batched entry (one workgroup per problem), the step cap every device loop carries, and the documented refusals."""
 import numpy as np
 import pytest
 
@@ -75,8 +76,8 @@ def test_refusals_and_limits(ctx):
     with pytest.raises(capi.EgsError) as e:      # lo must be <= 0 (toolkit/lcp.cc:448-450)
         ctx.box_lcp_dantzig(A, b, lo + 2.0, hi + 2.0)
     assert e.value.status == capi.ERR_INVALID
-    with pytest.raises(capi.EgsError) as e:      # beyond the single-wavefront limit
-        ctx.box_lcp_dantzig(spd(rng, 97, 0.1), np.zeros(97), -np.ones(97), np.ones(97))
+    with pytest.raises(capi.EgsError) as e:      # beyond the incremental solvers' limit (1024 rows)
+        ctx.box_lcp_dantzig(np.eye(1025), np.zeros(1025), -np.ones(1025), np.ones(1025))
     assert e.value.status == capi.ERR_INVALID
     ok, x, w, Ap, perm, piv = ctx.box_lcp_dantzig(A, b, lo, hi, max_steps=1)      # max_iterations-style give-up
     full = ctx.box_lcp_dantzig(A, b, lo, hi)
@@ -138,3 +139,80 @@ def test_repeated_calls_are_independent(ctx):
             for rep in range(4):
                 r = fn(np.tril(A), b, lo, hi)
                 assert r[0] and r[5] == o[5] and np.array_equal(r[4], o[4]) and np.array_equal(np.tril(r[3]), np.tril(o[3]))
+
+
+@pytest.mark.parametrize("n,alg", [(97, 1), (97, 0), (160, 1), (200, 0), (333, 1)])
+def test_beyond_the_lds_limit_the_same_steps(ctx, n, alg):
+    """n > 96: A is permuted in place in device memory, L in a work area, four wavefronts per problem -- the same
+    pivot sequence, permutation and matrix as the sequential restatement."""
+    rng = np.random.default_rng(500 + n)
+    A = spd(rng, n, 0.05)
+    b = rng.uniform(-2, 2, n)
+    lo = -rng.uniform(0.05, 2, n); hi = rng.uniform(0.05, 2, n)
+    hi[rng.uniform(size=n) < 0.3] = np.inf
+    marked = np.tril(A) + np.triu(np.full((n, n), 555.0), 1)
+    fn, ofn = ((ctx.box_lcp_murty, orc.tk_box_murty), (ctx.box_lcp_dantzig, orc.tk_box_dantzig))[alg]
+    ok, x, w, Ap, perm, piv = fn(marked, b, lo, hi)
+    oko, xo, wo, Ao, permo, pivo = ofn(np.tril(A), b, lo, hi)
+    assert ok and oko and piv == pivo and np.array_equal(perm, permo)
+    assert np.array_equal(np.triu(Ap, 1), np.triu(marked, 1))
+    assert np.array_equal(np.tril(Ap), np.tril(Ao))
+    assert np.abs(x - xo).max() < 1e-9 and np.abs(w - wo).max() < 1e-9
+    check_box_lcp(A, b, lo, hi, x, w)
+
+
+def test_batch_equals_the_single_calls(ctx):
+    """egs_box_lcp_batch: one workgroup per problem, mixed sizes (both instantiations in one call); every problem's
+    pivots, permutation, matrix and solution are those of its own single call and of the oracle."""
+    rng = np.random.default_rng(808)
+    sizes = [7, 24, 1, 96, 40, 130, 24, 12, 64, 97, 3]
+    for alg, ofn in ((1, orc.tk_box_dantzig), (0, orc.tk_box_murty)):
+        As, bs, los, his = [], [], [], []
+        for n in sizes:
+            As.append(np.tril(spd(rng, n, 0.05))); bs.append(rng.uniform(-2, 2, n))
+            los.append(-rng.uniform(0.05, 2, n)); his.append(rng.uniform(0.05, 2, n))
+        ok, x, w, Ap, perm, piv = ctx.box_lcp_batch(alg, As, bs, los, his)
+        for k, n in enumerate(sizes):
+            oko, xo, wo, Ao, permo, pivo = ofn(As[k], bs[k], los[k], his[k])
+            assert ok[k] and oko and piv[k] == pivo and np.array_equal(perm[k], permo), (alg, k)
+            assert np.array_equal(np.tril(Ap[k]), np.tril(Ao))
+            assert np.abs(x[k] - xo).max() < 1e-10 and np.abs(w[k] - wo).max() < 1e-10
+
+
+def test_batch_of_a_thousand_contact_sized_problems(ctx):
+    """1 536 problems of 24 rows (8 contacts x 3) in one launch: spot-checked against the oracle, all KKT-checked."""
+    rng = np.random.default_rng(909)
+    cnt, n = 1536, 24
+    As, bs, los, his = [], [], [], []
+    for k in range(cnt):
+        A = spd(rng, n, 0.1)
+        As.append(np.tril(A)); bs.append(rng.uniform(-1, 1, n))
+        los.append(np.tile([-1.0, -1.0, 0.0], n // 3)); his.append(np.tile([1.0, 1.0, np.inf], n // 3))   # the friction box of contact.cc:103-113
+    ok, x, w, Ap, perm, piv = ctx.box_lcp_batch(1, As, bs, los, his)
+    assert all(ok)
+    for k in range(cnt):
+        Af = As[k] + np.tril(As[k], -1).T
+        check_box_lcp(Af, bs[k], los[k], his[k], x[k], w[k])
+    for k in range(0, cnt, 97):
+        oko, xo, wo, Ao, permo, pivo = orc.tk_box_dantzig(As[k], bs[k], los[k], his[k])
+        assert piv[k] == pivo and np.array_equal(perm[k], permo) and np.abs(x[k] - xo).max() < 1e-11
+
+
+def test_every_device_loop_has_an_exit(ctx):
+    """A degenerate (singular PSD) matrix and a zero step budget: the call returns false / EGS_ERR_LCP_FAILED cleanly --
+    the device loop is capped at 20 n + 1000 steps where the reference's `while (true)` (toolkit/lcp.cc:493) has no cap."""
+    rng = np.random.default_rng(4242)
+    n = 30
+    V = rng.uniform(-1, 1, (n, 5))
+    A = V @ V.T                                        # rank 5: positive SEMI-definite, most pivots are ~0
+    b = rng.uniform(-1, 1, n)
+    lo = -np.ones(n); hi = np.ones(n)
+    for fn in (ctx.box_lcp_dantzig, ctx.box_lcp_murty):
+        ok, x, w, Ap, perm, piv = fn(np.tril(A), b, lo, hi)
+        assert piv <= 20 * n + 1001                    # whatever the outcome, the loop ended inside the cap
+        if ok:
+            check_box_lcp(A, b, lo, hi, x, w)
+    A = spd(rng, n, 0.05)
+    ok, x, w, Ap, perm, piv = ctx.box_lcp_batch(0, [np.tril(A)], [b], [lo], [hi], max_seconds=1e-9)     # Settings::max_time
+    full = ctx.box_lcp_murty(np.tril(A), b, lo, hi)
+    assert full[0] and (not ok[0] or full[5] <= 1)

@@ -167,3 +167,88 @@ def test_box_murty_agrees_with_dantzig_and_the_dense_murty_and_honours_the_limit
             assert ok2 and np.abs(x - x2).max() < 1e-8
             if iters > 1:      # max_iterations: gives up and returns false (toolkit/lcp.cc:438-441)
                 assert not orc.tk_box_murty(lower(A), b, lo, hi, max_iterations=iters - 1)[0]
+
+
+# ---- SolveLCP_BoxSchur, the reference's own test restated (toolkit/lcp.cc:1084-1200) ----------------------
+BIG = np.finfo(np.float64).max       # __DBL_MAX__: the reference's "infinity" in this test
+
+
+def test_box_schur_reference_test_restated():
+    rng = np.random.default_rng(11)
+    n = 20
+    A = spd(rng, n)                                   # A0 * A0', A0 = Random(n, n)   (:1086-1087)
+    b = rng.uniform(-1, 1, n)
+    x_full = np.linalg.solve(A, b)
+    assert np.linalg.norm(A @ x_full - b) < 1e-6       # :1099
+    lo = np.full(n, -BIG); hi = np.full(n, BIG)
+    # unbounded problem through the nub hook: nub == n (direct factor and solve) and nub == n / 2 (Schur complement);
+    # only the lower triangle is handed over (:1109-1110, 1131), w must be exactly 0 (:1118-1121, 1140-1143)
+    for nub in (n, n // 2):
+        ok, x, w, Ap, perm, nub_out, it = orc.tk_box_schur(lower(A), b, lo, hi, nub=nub)
+        assert ok and nub_out == nub
+        assert np.linalg.norm(x - x_full) < 1e-6
+        assert w.shape == x.shape and np.all(w == 0)
+    # a full box LCP with nub = 0 and nub = n / 2 (:1146-1173)
+    for start, end in ((0, n), (n // 4, n // 4 + n // 2)):
+        lo = np.full(n, -BIG); hi = np.full(n, BIG)
+        lo[start:end] = -rng.uniform(0, 1, end - start) * 10.0
+        hi[start:end] = rng.uniform(0, 1, end - start) * 10.0
+        ok, x, w, Ap, perm, nub_out, it = orc.tk_box_schur(lower(A), b, lo, hi)
+        assert ok
+        assert np.linalg.norm(A @ x - b - w) < 1e-6
+        assert np.all(x >= lo) and np.all(x <= hi)
+        assert nub_out == n - (end - start)
+    # random nub (:1176-1199)
+    for _ in range(100):
+        lo = np.full(n, -BIG); hi = np.full(n, BIG)
+        pick = rng.integers(0, 2, n) == 1
+        lo[pick] = -rng.uniform(0, 1, pick.sum()) * 10.0
+        hi[pick] = rng.uniform(0, 1, pick.sum()) * 10.0
+        ok, x, w, Ap, perm, nub_out, it = orc.tk_box_schur(lower(A), b, lo, hi)
+        assert ok
+        assert np.linalg.norm(A @ x - b - w) < 1e-6
+        assert np.all(x >= lo) and np.all(x <= hi)
+        assert nub_out == n - pick.sum()
+        # what the partition leaves in A: the symmetric permutation, lower triangle only; upper stays as given (0 here)
+        assert np.array_equal(np.tril(Ap), np.tril(A[np.ix_(perm, perm)])) or nub_out == 0
+        assert np.all(np.triu(Ap, 1) == 0)
+        # the unbounded rows come first
+        unb = ~pick
+        assert np.all(unb[perm[:nub_out]]) and not np.any(unb[perm[nub_out:]])
+
+
+def test_box_schur_both_inner_algorithms_and_the_box_conditions():
+    rng = np.random.default_rng(12)
+    for n in (5, 20, 60):
+        for trial in range(10):
+            A = spd(rng, n, 0.01)
+            b = rng.uniform(-1, 1, n)
+            lo = np.full(n, -np.inf); hi = np.full(n, np.inf)         # the real infinity is "infinity" too (toolkit/lcp.h:149-150)
+            pick = rng.uniform(size=n) < 0.6
+            lo[pick] = -rng.uniform(0.01, 1, pick.sum()); hi[pick] = rng.uniform(0.01, 1, pick.sum())
+            res = []
+            for alg in (0, 1):
+                ok, x, w, Ap, perm, nub, it = orc.tk_box_schur(lower(A), b, lo, hi, algorithm=alg)
+                assert ok and nub == n - pick.sum()
+                check_box_lcp(A, b, lo, hi, x, w)
+                res.append(x)
+            assert np.abs(res[0] - res[1]).max() < 1e-9               # one solution (A is SPD)
+            ok2, x2, w2, piv2 = orc.mixed_constraints(A, b, (~pick).astype(np.uint8), np.where(pick, lo, 0.0), np.where(pick, hi, 1.0), 1)
+            assert ok2 and np.abs(res[0] - x2).max() < 1e-8           # the dense restatement (lcp_dense.c), an independent route
+
+
+def test_box_schur_quirk_q6_classifies_by_the_lower_bound_alone():
+    # toolkit/lcp.cc:664, 669 test `hi < -DBL_MAX` / `hi >= -DBL_MAX`: a row with lo = -inf and a FINITE hi counts as
+    # unbounded in the reference (its hi is then never looked at); q6 = False classifies it as bounded
+    rng = np.random.default_rng(13)
+    n = 8
+    A = spd(rng, n, 0.1)
+    b = rng.uniform(0.5, 1, n) * 5
+    lo = np.full(n, -BIG); hi = np.full(n, BIG)
+    lo[:4] = -1.0; hi[:4] = 1.0
+    hi[6] = 0.01                                       # lo = -inf, hi finite
+    ok, x, w, Ap, perm, nub, it = orc.tk_box_schur(lower(A), b, lo, hi, q6=True)
+    assert ok and nub == 4
+    ok, x2, w2, Ap, perm, nub2, it = orc.tk_box_schur(lower(A), b, lo, hi, q6=False)
+    assert ok and nub2 == 3 and x2[6] <= 0.01 + 1e-15
+    check_box_lcp(A, b, lo, hi, x2, w2)
