@@ -169,6 +169,7 @@ struct DevBuf {
     p = nullptr;
     count = cap = 0;
   }
+  size_t bytes() const { return cap * sizeof(T); }
   ~DevBuf() { release(); }
 };
 
@@ -609,7 +610,12 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
   if (!(prm->tol > 0)) {
     // tickets are 32-bit counters that advance by cnt per sweep: very long runs
     // are cut into resumed launches so they cannot wrap
-    const int chunk_max = std::max(1, (int)(0xF0000000u / (uint32_t)std::max(1, (p->use_quad ? p->planq : p->plan).max_cnt)) - 2);
+    // ... and the static timetable counts time steps in a 32-bit int (t_end = depth + period x sweeps,
+    // step_solve.hip / quad_solve.hip): the chunk also keeps that below INT_MAX.  64-bit arithmetic, then the clamp.
+    const Plan &pl_used = p->use_quad ? p->planq : p->plan;
+    const int64_t by_ticket = (int64_t)0xF0000000u / (int64_t)std::max(1, pl_used.max_cnt) - 2;
+    const int64_t by_clock = ((int64_t)0x7fffffff - 2 * (int64_t)std::max(1, pl_used.max_depth) - 2) / (int64_t)std::max(1, pl_used.max_period) - 2;
+    const int chunk_max = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(by_ticket, by_clock), 0x7fffffff));
     int done = 0;
     do {
       const int chunk = std::min(chunk_max, prm->max_iters - done);
@@ -722,6 +728,13 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
       if (stop == chunk) break;   // the launch's own epilogue state is the answer
     }
     p->residual_pending = it > 0;   // res_partials still hold the sums of x0; x / wres are final
+    // the snapshots are scratch of THIS call: a problem object that once ran a tolerance-terminated solve on a large
+    // system must not keep up to 2 GiB of HBM (and the page-locked mirror) for the rest of its life.  Small ones stay
+    // (a converging Chain re-solves every step); the stream-ordered free waits for the kernels above.
+    if (p->hist_x.bytes() + p->hist_acc.bytes() > (size_t(64) << 20)) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      p->hist_x.release(); p->hist_acc.release(); p->hist_out.release();
+    }
   } else {
     while (!flag && err > prm->tol && it < prm->max_iters) {
       const int chunk = std::min(every, prm->max_iters - it);

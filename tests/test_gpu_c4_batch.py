@@ -27,17 +27,20 @@ def test_c4_full_batch_fp32(ctx):
     assert st.status == capi.OK and st.n_islands == 1024 * 16 and st.n_global == 0
     J0, J1, is_eq, lo, hi, rhs, err = pr.blocks()
     assert (lam >= lo).all() and (lam <= hi).all()
-    # piles 0, 511 and 1023 against the fp32 oracle, bit for bit
-    for k in (0, 511, 1023):
+    # EVERY one of the 1 024 ensembles against the fp32 oracle, bit for bit (0.4 ms each on the host)
+    Mi = Minv.reshape(n, 36)
+    lam32 = lam.astype(np.float32)
+    for k in range(1024):
         rows = slice(k * 256 * 3, (k + 1) * 256 * 3)
         cons = slice(k * 256, (k + 1) * 256)
-        s = orc.Sys(Minv.reshape(n, 36)[k * 64:(k + 1) * 64], np.where(sc["body0"][cons] >= 0, sc["body0"][cons] - 64 * k, -1),
+        s = orc.Sys(Mi[k * 64:(k + 1) * 64], np.where(sc["body0"][cons] >= 0, sc["body0"][cons] - 64 * k, -1),
                     sc["body1"][cons] - 64 * k, J0[cons], J1[cons], is_eq[rows], lo[rows], hi[rows])
         xo, ao, _, _ = orc.fast_iterate_f32(s, rhs[rows], 0.01, orc.GAUSS_SEIDEL, max_iters=50)
-        assert np.array_equal(lam[rows].astype(np.float32), xo)
-        # fp32 vs fp64 on the same inputs: stated tolerance 2e-3 relative
-        x64, _, _, _ = orc.fast_iterate(s, rhs[rows], 0.01, orc.GAUSS_SEIDEL, max_iters=50, tol=0.0)
-        assert np.abs(lam[rows] - x64).max() <= 2e-3 * max(1.0, np.abs(x64).max())
+        assert np.array_equal(lam32[rows], xo), k
+        if k % 128 == 0 or k == 1023:
+            # fp32 vs fp64 on the same inputs: stated tolerance 2e-3 relative
+            x64, _, _, _ = orc.fast_iterate(s, rhs[rows], 0.01, orc.GAUSS_SEIDEL, max_iters=50, tol=0.0)
+            assert np.abs(lam[rows] - x64).max() <= 2e-3 * max(1.0, np.abs(x64).max())
     pr.close()
 
 

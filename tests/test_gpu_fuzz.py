@@ -59,6 +59,14 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
             x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64, dirty=case % 2 == 1)
             assert st.status == capi.OK
             assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, quad, patch, step)
+        # the library's OWN choices: every schedule switch unset, so that use_static_timetable(), the occupancy gate of the
+        # 4-lane schedule, the isotropic cost model and the runs heuristic are fuzzed too (the legs above force each path)
+        for var in ("EGS_STEP", "EGS_QUAD", "EGS_PATCH", "EGS_QUAD_PATCH", "EGS_RUNS", "EGS_ISO"):
+            monkeypatch.delenv(var, raising=False)
+        x, a, st = run(ctx, s, rhs, method, K, cfm, capi.F64, dirty=case % 2 == 0)
+        assert st.status == capi.OK
+        assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, "defaults", st.schedule)
+        monkeypatch.setenv("EGS_RUNS", "1"); monkeypatch.setenv("EGS_ISO", "2" if case % 4 == 3 else "1")
         # the remaining legs alternate between the 4-lane kernel and the static timetable
         monkeypatch.setenv("EGS_QUAD", "1" if case % 2 == 0 else "0"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
         if case % 5 == 0 and cfm > 0:     # the reference's stopping loop (recorded chunks on the device)
