@@ -17,7 +17,7 @@ JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
 F64, F32 = 0, 1
 JOINT_BALL, CONTACT_BOX = 0, 1
 MV_LOWER, MV_UPPER, MV_DIAG, MV_FULL = 1, 2, 4, 8
-SCHED_QUAD, SCHED_ISO, SCHED_QUAD_PATCHES, SCHED_LANE_PATCHES, SCHED_ALL_GLOBAL, SCHED_STATIC = 1, 2, 4, 8, 16, 32
+SCHED_QUAD, SCHED_ISO, SCHED_QUAD_PATCHES, SCHED_LANE_PATCHES, SCHED_ALL_GLOBAL, SCHED_STATIC, SCHED_LEAN = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/eggshell_amd.h declares
 EXPORTS = [

@@ -214,6 +214,9 @@ struct egs_problem {
   // all-global kernel's persistent grid may have: both from the runtime's occupancy of the kernels
   int last_iso = 0;            // the last tile launch used the isotropic-body variant
   int last_static = 0;         // ... ran on the static timetable (step_solve.hip)
+  int last_lean = 0;           // ... in its 128-VGPR form (lean_solve.hip)
+  bool lin_antisym = false;    // J1_lin == -J0_lin on every two-body constraint (device assembly: by construction;
+                               // egs_problem_set_blocks: checked on the host), what lean_step_kernel relies on
   int oversize = 2;            // OversizeSchedule
   int global_max_blocks = 1;
   DevBuf<LaneDesc> q_lanes;
@@ -421,6 +424,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
           (p->hist_sweeps == 0 || (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)))) a.iso = 1;
     }
     p->last_iso = quad ? 0 : a.iso;
+    p->last_lean = 0;
     if (quad) {
       launch_cons_prepare<REAL>(a, ctx->stream);
       if (use_static_timetable(p->planq, sweeps)) {
@@ -435,8 +439,20 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
     } else if (method != EGS_JACOBI && use_static_timetable(p->plan, sweeps)) {
       a.lane_level = p->lane_level.p; a.tile_period = p->tile_period.p; a.tile_depth = p->tile_depth.p;
       a.runs = p->plan.runs ? 1 : 0;
-      launch_step_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
+      bool lean = false;
+      if constexpr (sizeof(REAL) == 8) {
+        // the 128-VGPR form (lean_solve.hip): an experiment switch, off by default -- measured on MI355X it buys residency
+        // (1024 instead of 768 constraints per CU) with a longer update and ends level with the 164-VGPR kernel
+        // (DESIGN.md section 5); EGS_LEAN=1 selects it wherever its preconditions hold.  Never for the
+        // snapshot-recording launches of the stopping loop.
+        const char *le = std::getenv("EGS_LEAN");
+        lean = le && std::atoi(le) != 0 && p->minv_iso && (p->plan.block == 256 || p->plan.block == 512) && p->lin_antisym &&
+               a.hist_x == nullptr && !a.runs;
+        if (lean) { a.iso = 1; launch_lean_solve(a, method, p->plan.n_tiles, p->plan.block, ctx->stream); p->last_iso = 1; }
+      }
+      if (!lean) launch_step_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
       p->last_static = 1;
+      p->last_lean = lean ? 1 : 0;
     } else {
       launch_tile_solve<REAL>(a, method, p->plan.n_tiles, p->plan.block, ctx->stream);
       p->last_static = 0;
@@ -576,7 +592,7 @@ void fill_stats(egs_problem *p, egs_solve_stats *st) {
   st->n_tiles = pl.n_tiles;
   st->n_global = (int32_t)pl.global.size();
   st->reserved = p->use_quad ? 1 : 0;  // 1: 4-lanes-per-constraint schedule for GS/SOR
-  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0) | (p->last_static ? EGS_SCHED_STATIC : 0);
+  st->schedule = (p->use_quad ? EGS_SCHED_QUAD : 0) | (p->last_iso ? EGS_SCHED_ISO : 0) | (p->last_static ? EGS_SCHED_STATIC : 0) | (p->last_lean ? EGS_SCHED_LEAN : 0);
   if (!p->use_quad && !pl.global.empty())
     st->schedule |= p->oversize == kQuadPatches ? EGS_SCHED_QUAD_PATCHES : p->oversize == kLanePatches ? EGS_SCHED_LANE_PATCHES : EGS_SCHED_ALL_GLOBAL;
   st->tile_constraints = pl.block;
@@ -777,6 +793,7 @@ void do_assemble(egs_problem *p, double dt, double erp) {
   else launch_assemble<double>(a, p->ctx->stream);
   HIPCHK(hipGetLastError());
   p->have_blocks = true;
+  p->lin_antisym = true;     // joints.cc:17-31 and contact.cc:66-99 build [X, ..] / [-X, ..]
 }
 
 void do_velocity(egs_problem *p, double dt) {
@@ -1230,6 +1247,17 @@ egs_status egs_problem_set_blocks(egs_problem *p, const double *Minv, const doub
     if (Minv && n) { upload(p->Minv_d, Minv, n * 36, p->ctx->stream); p->minv_r_valid = false; p->wf_valid = false; }
     upload_real(p, p->J0, J0, m * 18);
     upload_real(p, p->J1, J1, m * 18);
+    if (J0 || J1) {
+      // lean_step_kernel keeps ONE linear block per constraint: allowed only if J1_lin = -J0_lin wherever both sides exist
+      bool anti = J0 && J1 && p->precision == EGS_F64 && p->h_body0.size() == m && p->h_body1.size() == m;
+      for (size_t i = 0; anti && i < m; ++i) {
+        if (p->h_body0[i] < 0 || p->h_body1[i] < 0) continue;
+        for (int r = 0; r < 3 && anti; ++r)
+          for (int k = 0; k < 3; ++k)
+            if (!(J0[i * 18 + 6 * r + k] == -J1[i * 18 + 6 * r + k])) { anti = false; break; }
+      }
+      p->lin_antisym = anti;
+    }
     if (is_eq && m) upload(p->is_eq, is_eq, m * 3, p->ctx->stream);
     upload_real(p, p->lo, lo, m * 3);
     upload_real(p, p->hi, hi, m * 3);

@@ -90,6 +90,9 @@ void launch_tile_solve(const SolveArgs<REAL> &a, int method, int n_tiles,
 // the same GS / SOR sweep on the plan's static timetable: one workgroup barrier per time step, no tickets
 template <typename REAL>
 void launch_step_solve(const SolveArgs<REAL> &a, int method, int n_tiles, int block, hipStream_t s);
+// the same timetable in 128 VGPRs (lean_solve.hip): fp64, isotropic bodies, 256-constraint tiles, J1_lin = -J0_lin
+void launch_lean_solve(const SolveArgs<double> &a, int method, int n_tiles, int block, hipStream_t s);
+int occupancy_lean_solve(int block, int max_slots);
 // ... and the 4-lanes-per-constraint schedule on the same timetable (quad_solve.hip)
 template <typename REAL>
 void launch_step_quad(const SolveArgs<REAL> &a, int method, int n_tiles, int tile_size, hipStream_t s);

@@ -91,8 +91,10 @@ typedef enum {
   EGS_SCHED_QUAD_PATCHES = 4,  /* oversize islands: body patches on the 4-lane kernel */
   EGS_SCHED_LANE_PATCHES = 8,  /* oversize islands: body patches on the 1-lane kernel */
   EGS_SCHED_ALL_GLOBAL = 16,   /* oversize islands: the all-global kernel */
-  EGS_SCHED_STATIC = 32        /* step_solve_kernel / step_quad_kernel (with EGS_SCHED_QUAD): the plan's sweep on
+  EGS_SCHED_STATIC = 32,       /* step_solve_kernel / step_quad_kernel (with EGS_SCHED_QUAD): the plan's sweep on
                                   its static timetable (one workgroup barrier per time step) instead of tickets */
+  EGS_SCHED_LEAN = 64          /* lean_step_kernel: the timetable sweep in 128 VGPRs (one linear block for both sides,
+                                  constants parked in LDS): four 256-constraint tiles per CU (fp64, isotropic bodies) */
 } egs_schedule_flags;
 
 void egs_default_params(egs_solve_params *p); /* GS, 500, 1, omega 1.5, cfm 0, tol 1e-9 */

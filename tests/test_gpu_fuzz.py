@@ -67,6 +67,24 @@ def test_random_systems_all_schedules(ctx, seed, monkeypatch):
         assert st.status == capi.OK
         assert np.array_equal(x, xf, equal_nan=True) and np.array_equal(a, af, equal_nan=True), (seed, case, n, m, method, K, "defaults", st.schedule)
         monkeypatch.setenv("EGS_RUNS", "1"); monkeypatch.setenv("EGS_ISO", "2" if case % 4 == 3 else "1")
+        if case % 4 == 3 and method != capi.JACOBI:
+            # isotropic bodies: the 128-VGPR timetable kernel (lean_solve.hip), which needs J1_lin = -J0_lin -- true for the
+            # reference's constraint kinds, so give the random system that shape (and check that the switch is refused otherwise)
+            both = (s.body0 >= 0) & (s.body1 >= 0)
+            J0a = s.J0.copy().reshape(-1, 3, 6)
+            J0a[both, :, :3] = -s.J1.reshape(-1, 3, 6)[both, :, :3]
+            sa = orc.Sys(s.Minv, s.body0, s.body1, J0a.reshape(s.J0.shape), s.J1, s.is_eq, s.lo, s.hi)
+            xa, aa, _, _ = orc.fast_iterate(sa, rhs, cfm, method, max_iters=K, tol=0.0)
+            monkeypatch.setenv("EGS_LEAN", "1"); monkeypatch.setenv("EGS_QUAD", "0"); monkeypatch.setenv("EGS_STEP", "1")
+            for tile in ("256", "512"):
+                monkeypatch.setenv("EGS_TILE", tile)
+                x, a, st = run(ctx, sa, rhs, method, K, cfm, capi.F64)
+                assert np.array_equal(x, xa, equal_nan=True) and np.array_equal(a, aa, equal_nan=True), (seed, case, "lean", tile, st.schedule)
+                x, a, st2 = run(ctx, s, rhs, method, K, cfm, capi.F64)          # not antisymmetric: the switch must not apply
+                assert not (st2.schedule & capi.SCHED_LEAN) or not both.any()
+                assert np.array_equal(x, xf, equal_nan=True)
+            for var in ("EGS_LEAN", "EGS_TILE", "EGS_STEP"):
+                monkeypatch.delenv(var, raising=False)
         # the remaining legs alternate between the 4-lane kernel and the static timetable
         monkeypatch.setenv("EGS_QUAD", "1" if case % 2 == 0 else "0"); monkeypatch.setenv("EGS_PATCH", "1"); monkeypatch.setenv("EGS_QUAD_PATCH", "1")
         if case % 5 == 0 and cfm > 0:     # the reference's stopping loop (recorded chunks on the device)
