@@ -110,6 +110,71 @@ def measured_traffic_per_contact(kernel):
     return best
 
 
+def load_counters(case, kernel):
+    """Newest profiles/r*/counters.json entry for `case` of tools/pmc_case.py whose kernel is `kernel`: SQ counters
+    (mean per launch) and HBM bytes of exactly that workload, written by tools/profile_r3.sh + profile_summary.py."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json"))):
+        try:
+            e = json.load(open(f))["cases"].get(case)
+            k = e["kernels"].get(kernel) if e else None
+            if k and "valu_insts_per_launch" in k:
+                best = (k, e.get("contacts_per_launch"), os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
+# One dependent constraint update of the 1-lane sweep kernels, counted on the ISA of step_solve_kernel<double,256,1,true>
+# (DESIGN.md section 5): ds_read -> 3 (row product) + 2 (pair sums) + 1 (cfm fma) + 1 (rhs - ..) -> row 0: fma, cmp,
+# cndmask, cmp, cndmask, sub = 6 -> row 1: 1 + 6 -> row 2: 2 + 6 -> 1 (the accumulator fma that waits for dx2) -> ds_write
+# -> barrier.  29 dependent fp64 VALU operations and two LDS trips.
+DEPENDENT_VALU_OPS_PER_UPDATE = {"lane": 29, "quad": 24}
+
+
+def valu_roofline(kernel, kernel_ms, m, sweeps, prec, case, lat):
+    """The hardware-anchored bound of a sweep kernel: VALU issue.  achieved = VALU wave-instructions per launch (rocprofv3
+    SQ_INSTS_VALU of this very workload, committed under profiles/) / kernel time; peak = CUs x 4 SIMDs x clock / issue
+    cycles per wave-instruction (fp64: measured on this hardware with every SIMD kept busy, tools/microbench;
+    fp32: 64 lanes over a 16-wide SIMD).  Beside it: lane utilisation (how full the issued wavefronts were), the
+    ISA critical-path floor of one update, and the old latency model as `overlap_efficiency` (how well the tiles'
+    passes overlap -- measured against the kernel's own chain latency, hence not a roofline)."""
+    base = kernel.split("(")[0]
+    mb = load_profile_json("microbench.json")
+    clock_hz = (mb[0].get("memtime_ticks_per_us", 2400.0) if mb else 2400.0) * 1e6
+    if prec == "f64":
+        cyc = float(mb[0].get("fma_f64_issue_cycles_4_waves_per_simd", 6.76)) if mb else 6.76
+        cyc_src = ("%s:fma_f64_issue_cycles_4_waves_per_simd (v_fma_f64 back to back on every SIMD)" % mb[1]) if mb else "6.76 (DESIGN.md section 5)"
+        dep = float(mb[0].get("fma_f64_dependent_cycles", 6.0)) if mb else 6.0
+    else:
+        cyc, cyc_src, dep = 4.0, "64 lanes / 16 lanes per cycle per SIMD (architectural; fp32 not micro-benchmarked)", 4.0
+    peak = N_CU * 4 * clock_hz / cyc            # VALU wave-instructions per second, whole chip
+    c = load_counters(case, base) if case else None
+    out = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": peak / 1e9, "issue_cycles_per_instruction": cyc,
+           "issue_cycles_source": cyc_src, "clock_mhz": clock_hz / 1e6, "kernel": kernel, "kernel_ms": kernel_ms}
+    if c:
+        k, contacts, src = c
+        scale = float(m) / contacts if contacts else 1.0
+        valu = k["valu_insts_per_launch"] * scale
+        out.update({"achieved": valu / (kernel_ms * 1e-3) / 1e9, "frac": valu * cyc / (N_CU * 4 * kernel_ms * 1e-3 * clock_hz),
+                    "valu_insts_per_launch": valu, "lane_utilisation": k.get("lane_utilisation"),
+                    "valu_insts_per_update": valu / (float(m) * sweeps), "counters_source": "%s: case '%s' (%d contacts per launch%s)" % (
+                        src, case, contacts or 0, "" if abs(scale - 1.0) < 1e-9 else ", scaled x%.3f to this launch" % scale),
+                    "traffic": k.get("hbm_bytes_per_launch", 0.0) * scale if k.get("hbm_bytes_per_launch") else None,
+                    "wave_cycles_waiting_frac": (k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None})
+    else:
+        out.update({"achieved": None, "frac": None, "traffic": None,
+                    "note_counters": "no committed SQ counters for this workload (tools/profile_r3.sh %s)" % (case or "<case>")})
+    ops = DEPENDENT_VALU_OPS_PER_UPDATE["quad" if "quad" in base else "lane"]
+    lds = float(mb[0].get("ds_read_b32_dependent_cycles", 60.0)) if mb else 60.0
+    out["t_update_floor_us"] = (ops * dep + 2.0 * lds) / clock_hz * 1e6
+    out["t_update_floor_model"] = "%d dependent VALU operations x %.2f cycles + 2 LDS trips x %.0f cycles (ISA critical path of one update)" % (ops, dep, lds)
+    if lat:
+        out["overlap_efficiency"] = lat["frac"]
+        out["t_update_measured_us"] = lat["t_update_min_us"]
+    return out
+
+
 def sweep_critical_path(body0, body1, sweeps):
     """Length, in dependent constraint updates, of the list-order sweep's critical path:
     depth of one sweep's dependency DAG (a constraint waits for the previous constraint of
@@ -226,6 +291,18 @@ def rooflines(kernel, kernel_ms, launches, m, sweeps, prec, st, crit, case=None)
     return lat, hbm
 
 
+def hbm_roofline_from_counters(kernel, kernel_ms, m, case):
+    c = load_counters(case, kernel.split("(")[0])
+    if not c or not c[0].get("hbm_bytes_per_launch"):
+        return None
+    k, contacts, src = c
+    traffic = k["hbm_bytes_per_launch"] * (float(m) / contacts if contacts else 1.0)
+    gbs = traffic / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "%s: case '%s', %.0f B per contact per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                              % (src, case, traffic / m)}
+
+
 def build_problem(ctx, sc, precision):
     n = sc["p"].shape[0]
     Minv, f_ext = host_mass_and_force(sc)
@@ -276,9 +353,14 @@ def run_piles(ctx, workload, seeds, method, steps, warmup, torch=None, tdist=Non
     keep = (np.where(one["body0"] >= 0, one["body0"], one["body1"]) % col) == 0
     crit = sweep_critical_path(np.where(one["body0"][keep] >= 0, one["body0"][keep] // col, -1),
                                np.where(one["body1"][keep] >= 0, one["body1"][keep] // col, -1), sweeps)
-    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, prec, st, crit, case="c4" if workload == "c4" else None)
+    kname = solve_kernel_name(st)
+    lat, hbm = rooflines(kname, kernel_ms, launches, m, sweeps, prec, st, crit, case="c4" if workload == "c4" else None)
+    # which committed counter set belongs to this launch (tools/pmc_case.py): the headline batch, one pile, C2, C4
+    case = {"c4": "c4", "c2": "c2"}.get(workload, "quad" if len(piles) == 1 else "tile")
+    valu = valu_roofline(kname, kernel_ms, m, sweeps, prec, case, lat)
+    hbm = hbm_roofline_from_counters(kname, kernel_ms, m, case) or hbm
     return dict(elapsed=elapsed, n=sc["p"].shape[0], m=m, sweeps=sweeps, prec=prec, dt=dt, stats=st, t_plan=t_plan,
-                roofline=lat, roofline_hbm=hbm, shape=(nx, ny, nz), problem=pr, scene=sc, piles=len(piles))
+                roofline=valu, roofline_hbm=hbm, latency_model=lat, shape=(nx, ny, nz), problem=pr, scene=sc, piles=len(piles))
 
 
 def leg_from_run(r, steps, unit="pile-steps/s", note=None):
@@ -286,7 +368,7 @@ def leg_from_run(r, steps, unit="pile-steps/s", note=None):
            "contact_iters_per_sec": float(r["m"]) * r["sweeps"] * steps / r["elapsed"],
            "contacts": r["m"], "sweeps": r["sweeps"], "dtype": r["prec"], "islands": r["stats"].n_islands,
            "failed": r["stats"].status != capi.OK, "max_residual": r["stats"].residual,
-           "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"]}
+           "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "latency_model": r["latency_model"]}
     if note:
         out["note"] = note
     return out
@@ -367,27 +449,36 @@ def coupled_leg(ctx, method, steps, warmup, cpu_seconds):
     elapsed, kernel_ms, launches = time_region(ctx, lambda: pr.step(dt, 0.2, prm), steps, warmup)
     st = pr.stats()
     crit = sweep_critical_path(sc["body0"], sc["body1"], sweeps)
-    lat, hbm = rooflines(solve_kernel_name(st), kernel_ms, launches, m, sweeps, "f64", st, crit)
+    kname = solve_kernel_name(st)
+    lat, hbm = rooflines(kname, kernel_ms, launches, m, sweeps, "f64", st, crit)
+    valu = valu_roofline(kname, kernel_ms, m, sweeps, "f64", "coupled", lat)
+    hbm = hbm_roofline_from_counters(kname, kernel_ms, m, "coupled") or hbm
+    compulsory = float(m) * (36 + 3 + 3 + 3 + 3 + 3) * 8 + float(sc["p"].shape[0]) * (36 + 6) * 8     # J, rhs, bounds, lambda, w in/out; M^-1 block, accumulator
+    if hbm:
+        hbm["compulsory_bytes"] = compulsory
+        hbm["traffic_over_compulsory"] = hbm["traffic"] / compulsory
     out = {"value": steps / elapsed, "unit": "pile-steps/s", "ms_per_step": elapsed / steps * 1e3, "bodies": sc["p"].shape[0],
            "contacts": m, "islands": st.n_islands, "sweeps": sweeps, "contact_iters_per_sec": float(m) * sweeps * steps / elapsed,
-           "failed": st.status != capi.OK, "roofline": lat, "roofline_hbm": hbm,
+           "failed": st.status != capi.OK, "roofline": valu, "roofline_hbm": hbm, "latency_model": lat,
            "workload": "41 x 40 running-bond brick wall on the ground, contacts from the device collider: ONE island"}
     if cpu_seconds > 0:
         Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
         f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
-        done, t0 = 0, time.perf_counter()
-        while True:
-            J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
-            s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
-            rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
-            x, a, _, _ = orc.fast_iterate(s, rhs, 0.01, method, max_iters=sweeps, tol=0.0)
-            orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
-            done += 1
-            el = time.perf_counter() - t0
-            if el >= cpu_seconds or done >= 200:
-                break
+        with orc.timing_build() as flags:
+            done, t0 = 0, time.perf_counter()
+            while True:
+                J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+                s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+                rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
+                x, a, _, _ = orc.fast_iterate(s, rhs, 0.01, method, max_iters=sweeps, tol=0.0)
+                orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
+                done += 1
+                el = time.perf_counter() - t0
+                if el >= cpu_seconds or done >= 200:
+                    break
         out["cpu_baseline"] = {"value": done / el, "unit": "pile-steps/s", "cores": 1, "kind": "port",
-                               "sample": "%d steps of the same wall, oracle/ fast O(nnz) port, 1 thread, %.1f s" % (done, el)}
+                               "sample": "%d steps of the same wall, oracle/ fast O(nnz) port, 1 thread, %.1f s; build: %s" % (done, el, flags)}
+        out["gpu_over_cpu_1_core"] = out["value"] / out["cpu_baseline"]["value"]
     pr.close()
     return out
 
@@ -433,7 +524,12 @@ def c5_leg(ctx, cpu_seconds):
         fn(np.tril(A), b, lo96, hi96)
         t0 = time.perf_counter()
         ok, x, w, Ap, perm, piv = fn(np.tril(A), b, lo96, hi96)
-        out[name] = {"ms_per_solve": (time.perf_counter() - t0) * 1e3, "ok": bool(ok), "pivots": int(piv),
+        ofn = orc.tk_box_dantzig if "dantzig" in name else orc.tk_box_murty
+        tc = time.perf_counter()
+        ofn(np.tril(A), b, lo96, hi96)
+        tc = time.perf_counter() - tc
+        out[name] = {"ms_per_solve": (time.perf_counter() - t0 - tc) * 1e3, "ok": bool(ok), "pivots": int(piv),
+                     "cpu_port_ms_per_solve": tc * 1e3,
                      "kkt_residual": float(np.abs(A @ x - b - w).max()),
                      "includes": "upload + one single-wavefront launch + download (toolkit/lcp.cc:213-619 semantics, A permuted in place)"}
     out["note"] = ("reference_rule = Murty single-index principal pivoting as lcp.cc:157-274 (cap min(1000, 2^n) pivots: it "
@@ -449,6 +545,42 @@ def c5_leg(ctx, cpu_seconds):
             cpu["N%d" % N] = {"ms_per_solve": (time.perf_counter() - t0) * 1e3, "ok": bool(ok), "pivots": int(piv)}
         out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms/solve", "sample": "oracle/lcp_dense.c (restated "
                                "MixedConstraintsSolver + Murty, lcp.cc:141-336), one solve each", **cpu}
+    return out
+
+
+def lcp_batch_leg(ctx, cpu_seconds, count=2048, n=24):
+    """toolkit/lcp.cc's incremental-factor box LCP as a BATCH: `count` independent problems of n rows (8 contacts x 3
+    with the friction box of contact.cc:103-113) in one launch, one workgroup per problem (egs_box_lcp_batch) -- what a
+    batch of ensembles hands lcp::SolveLCP; the CPU figure is the oracle's restatement of the same algorithm."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    As, bs, los, his = [], [], [], []
+    for k in range(count):
+        M = rng.uniform(-1, 1, (n, n))
+        As.append(np.tril(M @ M.T + 0.1 * np.eye(n))); bs.append(rng.uniform(-1, 1, n))
+        los.append(np.tile([-1.0, -1.0, 0.0], n // 3)); his.append(np.tile([1.0, 1.0, np.inf], n // 3))
+    out = {"problems": count, "rows": n, "includes": "upload of the %d matrices + one launch + download (host arrays in, host arrays out)" % count}
+    ns = np.full(count, n, np.int32)
+    Ap_, bp_, lop_, hip_ = np.concatenate([a.reshape(-1) for a in As]), np.concatenate(bs), np.concatenate(los), np.concatenate(his)
+    for name, alg in (("box_dantzig", 1), ("box_murty", 0)):
+        ctx.box_lcp_batch(alg, As[:8], bs[:8], los[:8], his[:8])
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ok, x, w, Ap, perm, piv = ctx.box_lcp_batch_packed(alg, ns, Ap_, bp_, lop_, hip_)
+            best = min(best, time.perf_counter() - t0)
+        out[name] = {"problems_per_sec": count / best, "ms_per_batch": best * 1e3, "all_ok": bool(all(ok)), "pivots_mean": float(np.mean(piv))}
+        if cpu_seconds > 0:
+            fn = orc.tk_box_dantzig if alg == 1 else orc.tk_box_murty
+            with orc.timing_build() as flags:
+                done, t0 = 0, time.perf_counter()
+                while done < count and time.perf_counter() - t0 < min(2.0, cpu_seconds):
+                    fn(As[done], bs[done], los[done], his[done])
+                    done += 1
+                el = time.perf_counter() - t0
+            out[name]["cpu_baseline"] = {"value": done / el, "unit": "problems/s", "cores": 1, "kind": "port",
+                                         "sample": "%d of the same problems, oracle/lcp_toolkit.c, 1 thread, %.2f s (ctypes call overhead included); build: %s" % (done, el, flags)}
+            out[name]["gpu_over_cpu_1_core"] = out[name]["problems_per_sec"] / (done / el)
     return out
 
 
@@ -553,30 +685,38 @@ def c1_leg(ctx, cpu_seconds):
 
 def cpu_baseline(workload, budget_s):
     """Single-thread CPU port (oracle/, the fast O(nnz) sequential PGS in list order + assembly +
-    velocity update) on ONE pile of the same workload."""
+    velocity update) on ONE pile of the same workload.  Timed on the oracle sources built with the REFERENCE's
+    flags (liboracle_refflags.so: -O2 -DNDEBUG, GCC's default contraction); the parity build (-ffp-contract=off,
+    the checker) is timed beside it for 2 s."""
     from oracle import oracle as orc
     nx, ny, nz, sweeps, prec, dt = WORKLOADS[workload]
     sc = scenes.box_stack(nx, ny, nz)
-    Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
-    f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
-    done, t0 = 0, time.perf_counter()
-    while True:
-        J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
-        s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
-        rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
-        if prec == "f32":
-            x, a, _, _ = orc.fast_iterate_f32(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps)
-        else:
-            x, a, _, _ = orc.fast_iterate(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps, tol=0.0)
-        orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 1000:
-            break
+
+    def run(budget):
+        Minv = orc.minv_blocks(sc["R"], sc["mass"], sc["I_body"])
+        f_ext = orc.external_force(sc["R"], sc["w"], sc["mass"], sc["I_body"])
+        done, t0 = 0, time.perf_counter()
+        while True:
+            J0, J1, is_eq, lo, hi, err = orc.assemble(sc["p"], sc["R"], sc["kind"], sc["body0"], sc["body1"], sc["data"])
+            s = orc.Sys(Minv, sc["body0"], sc["body1"], J0, J1, is_eq, lo, hi)
+            rhs = orc.ode_rhs(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, err, dt, 0.2)
+            if prec == "f32":
+                x, a, _, _ = orc.fast_iterate_f32(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps)
+            else:
+                x, a, _, _ = orc.fast_iterate(s, rhs, 0.01, orc.GAUSS_SEIDEL, max_iters=sweeps, tol=0.0)
+            orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= budget or done >= 1000:
+                return done, el, s.m
+    with orc.timing_build() as flags:
+        done, el, m = run(budget_s)
+    done_p, el_p, _ = run(min(2.0, budget_s))
     unit = "ensemble-steps/s" if workload == "c4" else "pile-steps/s"
     return {"value": done / el, "unit": unit, "cores": 1, "kind": "port",
             "sample": "%d steps of one %dx%dx%d pile (%d contacts, GS %d sweeps, %s), oracle/ fast O(nnz) "
-                      "port, gcc -O2, 1 thread, %.1f s" % (done, nx, ny, nz, s.m, sweeps, prec, el)}
+                      "port, 1 thread, %.1f s; build: %s" % (done, nx, ny, nz, m, sweeps, prec, el, flags),
+            "parity_build_value": done_p / el_p, "parity_build_flags": orc.BUILD_FLAGS["parity"]}
 
 
 def cpu_baseline_threads(workload, budget_s, threads):
@@ -602,11 +742,13 @@ def cpu_baseline_threads(workload, budget_s, threads):
             orc.velocity_update(sc["v"], sc["w"], Minv, f_ext, s.body0, s.body1, J0, J1, x, dt)
             counts[k] += 1
 
-    ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
+    with orc.timing_build():          # the reference-flag build, as cpu_baseline()
+        t_start = time.perf_counter()
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
     el = time.perf_counter() - t_start
     return {"value": sum(counts) / el, "unit": "ensemble-steps/s" if workload == "c4" else "pile-steps/s", "cores": threads,
             "kind": "port", "sample": "%d steps on %d threads, one %dx%dx%d pile each, %.1f s (measured)" % (sum(counts), threads, nx, ny, nz, el)}
@@ -702,7 +844,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"], help="the headline workload (`value`)")
     ap.add_argument("--method", default="gs", choices=["gs", "sor"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
-    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,literal,stopping_loop,world (1 GPU only)")
+    ap.add_argument("--legs", default="all", help="'all', 'none' or a comma list of single_pile,matvec,c1,c2,c4,coupled,c5,lcp_batch,literal,stopping_loop,world (1 GPU only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -728,7 +870,7 @@ def main():
     ctx = capi.Context(dev)       # raises without the HIP library / a GPU: no fallback
     method = capi.GAUSS_SEIDEL if args.method == "gs" else capi.SOR
     legs = set() if (args.legs == "none" or world > 1) else \
-        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "literal", "stopping_loop", "world"} if args.legs == "all" else set(args.legs.split(",")))
+        ({"single_pile", "matvec", "c1", "c2", "c4", "coupled", "c5", "lcp_batch", "literal", "stopping_loop", "world"} if args.legs == "all" else set(args.legs.split(",")))
 
     if args.workload == "c4":     # BASELINE config 4: 1024 ensembles sharded over the ranks
         seeds, scaling, unit = c4_shard_seeds(rank, world), "strong", "ensemble-steps/s"
@@ -774,6 +916,7 @@ def main():
             "failed": failed,
             "roofline": r["roofline"],
             "roofline_hbm": r["roofline_hbm"],
+            "latency_model": r["latency_model"],
         }
     if rank == 0 and world == 1:
         extra = {}
@@ -805,6 +948,8 @@ def main():
             extra["coupled"] = coupled_leg(ctx, method, max(5, args.steps // 2), 2, min(5.0, args.cpu_seconds))
         if "c5" in legs:
             extra["c5"] = c5_leg(ctx, args.cpu_seconds)
+        if "lcp_batch" in legs:
+            extra["lcp_batch"] = lcp_batch_leg(ctx, args.cpu_seconds)
         if "stopping_loop" in legs:
             extra["stopping_loop"] = stopping_loop_leg(ctx)
         if "world" in legs:
@@ -833,7 +978,26 @@ def main():
             if "literal" in legs:
                 out["cpu_baseline_literal"] = cpu_literal_baseline(args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # every leg's fractions in one small object right behind the headline figures, so that a truncated record of
+        # this line still carries them (each is recomputable from profiles/: see roofline.counters_source)
+        def fr(leg, key="roofline"):
+            o = out if leg is None else out.get(leg)
+            o = o.get(key) if isinstance(o, dict) else None
+            return None if not isinstance(o, dict) or o.get("frac") is None else round(float(o["frac"]), 4)
+        summary = {"headline_valu_issue": fr(None), "headline_hbm": fr(None, "roofline_hbm"),
+                   "headline_lane_utilisation": (out.get("roofline") or {}).get("lane_utilisation")}
+        for leg in ("single_pile", "c2", "c4", "coupled"):
+            if leg in out:
+                summary[leg + "_valu_issue"] = fr(leg)
+                summary[leg + "_hbm"] = fr(leg, "roofline_hbm")
+        if "matvec" in out:
+            summary["matvec_hbm"] = fr("matvec")
+        head = {}
+        for k, v in out.items():
+            head[k] = v
+            if k == "ms_per_step":
+                head["roofline_summary"] = summary
+        print(json.dumps(head), flush=True)
     ctx.close()
     if world > 1:
         tdist.destroy_process_group()

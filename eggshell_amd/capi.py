@@ -212,17 +212,27 @@ class Context:
             self.check(st)
         return bool(ok.value), x, w, A, perm, piv.value
 
-    def box_lcp_batch(self, algorithm, As, bs, los, his, max_steps=0, max_seconds=0.0):
-        """`len(As)` independent box LCPs in one launch (egs_box_lcp_batch); algorithm 0 = BoxMurty, 1 = BoxDantzig.
-        Returns lists ok, x, w, A (permuted in place), perm, pivots -- problem k's entries equal its single call's."""
-        ns = np.array([len(b) for b in bs], np.int32)
-        A = np.concatenate([_f64(a).reshape(-1) for a in As]).copy()
-        b, lo, hi = (np.concatenate([_f64(v) for v in vs]) for vs in (bs, los, his))
+    def box_lcp_batch_packed(self, algorithm, ns, A, b, lo, hi, max_steps=0, max_seconds=0.0):
+        """egs_box_lcp_batch on packed arrays (problem k's matrix at sum_{j<k} n_j^2, its vectors at sum_{j<k} n_j):
+        returns ok, x, w, A (permuted in place, a copy), perm, pivots -- packed the same way."""
+        ns = _i32(ns)
+        A = _f64(A).copy()
+        b, lo, hi = map(_f64, (b, lo, hi))
         tot, cnt = int(ns.sum()), len(ns)
         x = np.zeros(tot); w = np.zeros(tot); perm = np.zeros(tot, np.int32)
         ok = np.zeros(cnt, np.int32); piv = np.zeros(cnt, np.int32)
         self.check(load().egs_box_lcp_batch(self.h, C.c_int32(algorithm), C.c_int32(cnt), _p(ns), _p(A), _p(b), _p(lo), _p(hi),
                                             C.c_int32(max_steps), C.c_double(max_seconds), _p(x), _p(w), _p(perm), _p(ok), _p(piv)))
+        return ok, x, w, A, perm, piv
+
+    def box_lcp_batch(self, algorithm, As, bs, los, his, max_steps=0, max_seconds=0.0):
+        """`len(As)` independent box LCPs in one launch (egs_box_lcp_batch); algorithm 0 = BoxMurty, 1 = BoxDantzig.
+        Returns lists ok, x, w, A (permuted in place), perm, pivots -- problem k's entries equal its single call's."""
+        ns = np.array([len(b) for b in bs], np.int32)
+        A = np.concatenate([_f64(a).reshape(-1) for a in As])
+        b, lo, hi = (np.concatenate([_f64(v) for v in vs]) for vs in (bs, los, his))
+        cnt = len(ns)
+        ok, x, w, A, perm, piv = self.box_lcp_batch_packed(algorithm, ns, A, b, lo, hi, max_steps, max_seconds)
         vo = np.concatenate([[0], np.cumsum(ns)]); ao = np.concatenate([[0], np.cumsum(ns.astype(np.int64) ** 2)])
         return ([bool(v) for v in ok], [x[vo[k]:vo[k + 1]] for k in range(cnt)], [w[vo[k]:vo[k + 1]] for k in range(cnt)],
                 [A[ao[k]:ao[k + 1]].reshape(ns[k], ns[k]) for k in range(cnt)], [perm[vo[k]:vo[k + 1]] for k in range(cnt)],

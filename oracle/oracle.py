@@ -32,6 +32,34 @@ def lib():
     return _LIB
 
 
+_LIB_PARITY = None
+BUILD_FLAGS = {"parity": "gcc -O2 -DNDEBUG -march=x86-64-v3 -ffp-contract=off (the checker's build: roundings = the HIP kernels')",
+               "refflags": "gcc -O2 -DNDEBUG -march=x86-64-v3, GCC's default contraction (-ffp-contract=fast): the reference's "
+                           "flags (common.mk:159-160, 187-188) with x86-64-v3 standing in for -march=native"}
+
+
+class timing_build:
+    """`with orc.timing_build() as flags:` -- inside the block every oracle call runs in liboracle_refflags.so, the
+    same sources built with the reference's flags (oracle/Makefile).  For TIMING the CPU baseline only: results of
+    that build are not used to check anything."""
+
+    def __enter__(self):
+        global _LIB, _LIB_PARITY
+        so = os.path.join(_HERE, "liboracle_refflags.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_refflags.so"])
+        lib()
+        _LIB_PARITY = _LIB
+        _LIB = C.CDLL(so)
+        _LIB.orc_lit_residual.restype = C.c_double
+        return BUILD_FLAGS["refflags"]
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = _LIB_PARITY
+        return False
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

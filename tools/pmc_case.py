@@ -7,7 +7,7 @@
     python3 tools/pmc_summary.py gpurun_out/pmc_f_tile gpurun_out/pmc_w_tile profiles/r02/pmc_traffic.json 393216 tile_solve_kernel
 
 cases: tile (24 C3 piles, the bench headline) | quad (1 C3 pile) | matvec (64 C3 piles, the product)
-       | coupled (the 41 x 40 wall, one island) | c4 (1024 x 64-body ensembles fp32)"""
+       | coupled (the 41 x 40 wall, one island) | c4 (1024 x 64-body ensembles fp32) | c2 (one 256-body pile)"""
 import os
 import sys
 
@@ -23,8 +23,8 @@ def main():
     case = sys.argv[1]
     launches = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     ctx = capi.Context(0)
-    if case in ("tile", "quad", "c4"):
-        wl = "c4" if case == "c4" else "c3"
+    if case in ("tile", "quad", "c4", "c2"):
+        wl = "c4" if case == "c4" else ("c2" if case == "c2" else "c3")
         seeds = bench.c4_shard_seeds(0, 1) if case == "c4" else ([b + 1 for b in range(24)] if case == "tile" else [1])
         r = bench.run_piles(ctx, wl, seeds, capi.GAUSS_SEIDEL, launches, 1)
         print("contacts", r["m"], "kernel", bench.solve_kernel_name(r["stats"]))
