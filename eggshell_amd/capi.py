@@ -34,7 +34,7 @@ EXPORTS = [
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
     "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig", "egs_box_lcp_murty",
-    "egs_box_lcp_batch", "egs_box_lcp_schur",
+    "egs_box_lcp_batch", "egs_box_lcp_schur", "egs_dense_condition",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -194,6 +194,13 @@ class Context:
             self.check(st)
         return bool(ok.value), x, w, piv.value
 
+
+    def dense_condition(self, A):
+        """GetConditionNumber of a symmetric positive definite matrix (utils.cc:256-261) on the device: (estimate, pivot bound)."""
+        A = _f64(A)
+        est, pb = C.c_double(0), C.c_double(0)
+        self.check(load().egs_dense_condition(self.h, C.c_int32(A.shape[0]), _p(A), C.byref(est), C.byref(pb)))
+        return est.value, pb.value
 
     def box_lcp_murty(self, A, b, lo, hi, max_iterations=0):
         """lcp::SolveLCP_BoxMurty on a LinearReducer (toolkit/lcp.cc:213-328, 380-442), n <= 1024."""

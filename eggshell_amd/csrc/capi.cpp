@@ -1529,6 +1529,22 @@ egs_status egs_problem_dense_condition(egs_problem *p, double cfm, double *estim
   });
 }
 
+egs_status egs_dense_condition(egs_context *ctx, int32_t N, const double *A, double *estimate, double *pivot_bound) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (N < 0 || !estimate || (N > 0 && !A)) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf<double> dA;
+    dA.alloc((size_t)N * N);
+    if (N) HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    bool spd = true;
+    double pb = 1.0;
+    *estimate = dense_condition_estimate(ctx->stream, N, dA.p, &spd, &pb);
+    if (pivot_bound) *pivot_bound = spd ? pb : *estimate;
+    return EGS_OK;
+  });
+}
+
 egs_status egs_problem_step_dense(egs_problem *p, double dt, double erp, double cfm, int32_t use_bounds, int32_t *ok,
                                   int32_t *pivots) {
   if (!p) return EGS_ERR_INVALID;

@@ -25,10 +25,12 @@ bool dense_mixed_constraints_device(hipStream_t stream, int N, const double *dA,
                                     const double *lo, const double *hi, bool use_bounds, bool block_pivoting,
                                     int max_pivots, double max_seconds, double *x, double *w, double *dx_out,
                                     int *pivots, std::string *msg);
-// Condition estimate of a symmetric positive definite device matrix from its Cholesky factor:
-// (max_i L_ii / min_i L_ii)^2, a lower bound of the 2-norm condition number the reference gets from
-// a JacobiSVD (utils.cc:256-261).  *spd = false (and +inf) if the factorisation breaks down.
-double dense_condition_estimate(hipStream_t stream, int N, const double *dA, bool *spd);
+// 2-norm condition number of a symmetric positive definite device matrix, what the reference gets from a JacobiSVD
+// (utils.cc:256-261): lambda_max by power iteration on A times 1 / lambda_min by inverse iteration with the blocked
+// Cholesky factor (N <= 1024; 60 iterations each, accurate to a few per cent unless the extreme eigenvalues are
+// clustered, and never above the true value).  *pivot_bound (may be NULL) = (max L_ii / min L_ii)^2, the cheap lower
+// bound, which is also what is returned beyond 1024 rows.  *spd = false (and +inf) if the factorisation breaks down.
+double dense_condition_estimate(hipStream_t stream, int N, const double *dA, bool *spd, double *pivot_bound = nullptr);
 
 // lcp::SolveLCP_BoxDantzig / SolveLCP_BoxMurty with the incremental Cholesky factor of toolkit/lcp.cc (dantzig.hip):
 // one workgroup per problem.  n <= kDantzigMaxRows: one wavefront, everything in LDS; up to kIncrementalMaxRows:

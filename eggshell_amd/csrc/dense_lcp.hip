@@ -27,6 +27,7 @@
 // failure instead of a wrong answer.
 #include "dense_lcp.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -908,8 +909,18 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
                              std::string *msg, int max_pivots, double max_seconds) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
+  const bool trace = std::getenv("EGS_DENSE_TRACE") != nullptr;
+  const auto t_a = std::chrono::steady_clock::now();
   Buf<double> dA((size_t)N * N), db(N);
+  const auto t_b = std::chrono::steady_clock::now();
+  // (a pageable source: ROCm 7.2 moves these 33.6 MB in 0.6 ms on MI355X's host; a hand-made threaded staging copy took 0.9)
   HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+  if (trace) {
+    HIPCHK(hipStreamSynchronize(s));
+    const auto t_c = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "dense trace N=%d: alloc %.3f ms, upload %.3f ms\n", N, std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+                 std::chrono::duration<double, std::milli>(t_c - t_b).count());
+  }
   HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
   return dense_mixed_constraints_device(s, N, dA.p, db.p, C, lo, hi, use_bounds, block_pivoting, max_pivots, max_seconds, x, w,
                                         nullptr, pivots, msg);
@@ -941,11 +952,117 @@ __global__ void __launch_bounds__(256) diag_minmax_kernel(const double *T, int l
   if (threadIdx.x == 0) { out[0] = smax[0]; out[1] = smin[0]; }
 }
 
-double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *spd) {
+// lambda_max(A) by power iteration and 1 / lambda_min(A) by inverse iteration with the blocked Cholesky factor held in
+// T (ld = npad, identity padding) and its inverted diagonal blocks: cond_2(A) = lambda_max / lambda_min for a symmetric
+// positive definite A -- what the reference reads off a JacobiSVD (utils.cc:256-261: sigma_max / sigma_min).  One
+// workgroup, N <= 1024: every vector in LDS, a thread per row for the products, 64-row block steps for the two
+// triangular solves.  out[0] = lambda_max estimate, out[1] = 1 / lambda_min estimate (Rayleigh quotients, both from below).
+constexpr int kCondMaxRows = 1024;
+__global__ void __launch_bounds__(1024) cond_iterations_kernel(const double *A, int N, const double *T, int ld, int npad, const double *inv,
+                                                               int iters, double *out) {
+  __shared__ double v[kCondMaxRows], u[kCondMaxRows], red[1024], part[16][NB], blk[NB];
+  const int tid = threadIdx.x;
+  auto dot = [&](const double *a, const double *b) {
+    double sacc = 0.0;
+    for (int i = tid; i < N; i += 1024) sacc = __builtin_fma(a[i], b[i], sacc);
+    red[tid] = sacc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  auto start = [&]() {     // a start vector with a component along every eigenvector one can reasonably expect
+    for (int i = tid; i < npad; i += 1024) v[i] = i < N ? 1.0 + 0.37 * (double)((unsigned)(i * 2654435761u) >> 22) / 1024.0 : 0.0;
+    __syncthreads();
+  };
+  // ---- lambda_max
+  start();
+  double lmax = 0.0;
+  for (int it = 0; it < iters; ++it) {
+    for (int r = tid; r < N; r += 1024) {
+      double sacc = 0.0;
+      const double *row = A + (size_t)r * N;
+      for (int c = 0; c < N; ++c) sacc = __builtin_fma(row[c], v[c], sacc);
+      u[r] = sacc;
+    }
+    __syncthreads();
+    const double vv = dot(v, v), vu = dot(v, u), uu = dot(u, u);
+    lmax = vu / vv;
+    const double sc = uu > 0.0 ? 1.0 / sqrt(uu) : 0.0;
+    for (int i = tid; i < N; i += 1024) v[i] = u[i] * sc;
+    __syncthreads();
+  }
+  // ---- 1 / lambda_min: z = A^-1 v = L^-T L^-1 v
+  start();
+  double mu = 0.0;
+  const int i64 = tid & 63, p16 = tid >> 6;
+  for (int it = 0; it < iters; ++it) {
+    for (int i = tid; i < npad; i += 1024) u[i] = v[i];
+    __syncthreads();
+    for (int kb = 0; kb < npad; kb += NB) {            // L y = u, block by block: y_kb = Linv_kb u_kb, then the strip below
+      const double *Li = inv + (size_t)(kb / NB) * NB * NB;
+      double sacc = 0.0;
+      for (int c = p16; c < NB; c += 16) sacc = __builtin_fma(Li[i64 * NB + c], u[kb + c], sacc);     // Linv[r][c] = 0 for c > r
+      part[p16][i64] = sacc;
+      __syncthreads();
+      if (tid < NB) {
+        double y = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y += part[q][tid];
+        blk[tid] = y;
+        u[kb + tid] = y;
+      }
+      __syncthreads();
+      for (int i = kb + NB + tid; i < npad; i += 1024) {
+        double y = u[i];
+        const double *row = T + (size_t)i * ld + kb;
+#pragma unroll 16
+        for (int c = 0; c < NB; ++c) y = __builtin_fma(-row[c], blk[c], y);
+        u[i] = y;
+      }
+      __syncthreads();
+    }
+    for (int kb = npad - NB; kb >= 0; kb -= NB) {      // L^T z = y: z_kb = Linv_kb^T y_kb, then the strip to its left
+      const double *Li = inv + (size_t)(kb / NB) * NB * NB;
+      double sacc = 0.0;
+      for (int r = p16; r < NB; r += 16) sacc = __builtin_fma(Li[r * NB + i64], u[kb + r], sacc);
+      part[p16][i64] = sacc;
+      __syncthreads();
+      if (tid < NB) {
+        double z = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) z += part[q][tid];
+        blk[tid] = z;
+        u[kb + tid] = z;
+      }
+      __syncthreads();
+      for (int c = tid; c < kb; c += 1024) {
+        double y = u[c];
+#pragma unroll 16
+        for (int r = 0; r < NB; ++r) y = __builtin_fma(-T[(size_t)(kb + r) * ld + c], blk[r], y);
+        u[c] = y;
+      }
+      __syncthreads();
+    }
+    const double vv = dot(v, v), vu = dot(v, u), uu = dot(u, u);
+    mu = vu / vv;
+    const double sc = uu > 0.0 ? 1.0 / sqrt(uu) : 0.0;
+    for (int i = tid; i < npad; i += 1024) v[i] = i < N ? u[i] * sc : 0.0;
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = lmax; out[1] = mu; }
+}
+
+double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *spd, double *pivot_bound) {
   if (spd) *spd = true;
+  if (pivot_bound) *pivot_bound = 1.0;
   if (N == 0) return 1.0;
   const int npad = (N + NB - 1) / NB * NB;
-  Buf<double> T((size_t)(npad + 1) * npad), dinv((size_t)npad * NB), zero(N), mm(2);
+  Buf<double> T((size_t)(npad + 1) * npad), dinv((size_t)npad * NB), zero(N), mm(4);
   Buf<int> idx_d(N), fail_d(1);
   std::vector<int> idx(N);
   for (int i = 0; i < N; ++i) idx[i] = i;
@@ -955,14 +1072,21 @@ double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *sp
   hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p);
   factor(s, T.p, npad, npad + 1, npad, fail_d.p, dinv.p);
   hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, s, T.p, npad, N, mm.p);
-  double h[2] = {1, 1};
+  double h[4] = {1, 1, 0, 0};
   int fail = 0;
-  HIPCHK(hipMemcpyAsync(h, mm.p, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h, mm.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof fail, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (fail || !(h[1] > 0)) { if (spd) *spd = false; return std::numeric_limits<double>::infinity(); }
   const double r = h[0] / h[1];
-  return r * r;
+  if (pivot_bound) *pivot_bound = r * r;
+  if (N > kCondMaxRows) return r * r;      // beyond one workgroup's vectors: the pivot bound (a LOWER bound) is all there is
+  // 60 iterations each: the Rayleigh quotients converge like (lambda_2 / lambda_1)^(2k); both approach from below
+  hipLaunchKernelGGL(cond_iterations_kernel, dim3(1), dim3(1024), 0, s, dA, N, T.p, npad, npad, dinv.p, 60, mm.p + 2);
+  HIPCHK(hipMemcpyAsync(h + 2, mm.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double est = h[2] * h[3];
+  return est > r * r ? est : r * r;          // two lower bounds: the larger one
 }
 
 bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, const double *db_in, const uint8_t *C,

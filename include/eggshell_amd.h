@@ -268,12 +268,18 @@ egs_status egs_mixed_constraints_solve_limits(egs_context *ctx, int32_t N, const
  *      A = J M^-1 J^T + cfm I (ensembles.cc:510, 513-521), [3m][3m] row-major,
  *      kept on the device; A (host) may be NULL.  fp64 problems only.          */
 egs_status egs_problem_dense_system(egs_problem *p, double cfm, double *A /*[3m][3m] or NULL*/);
-/* What stands in for CheckMatrixCondition (ensembles.cc:514 -> utils.cc:256-287):
- * the reference takes the 2-norm condition number from a JacobiSVD (Eigen, absent
- * here); this returns (max L_ii / min L_ii)^2 of the Cholesky factor of A, a lower
- * bound of it -- +inf when A is not positive definite.  The caller compares with
- * kGoodConditionNumber = 1e7 (constants.h:12) and picks the cfm of the step.     */
+/* Replaces CheckMatrixCondition / GetConditionNumber (ensembles.cc:514 -> utils.cc:256-287): the
+ * reference takes sigma_max / sigma_min from a JacobiSVD (Eigen, absent here).  For the symmetric
+ * positive definite A that is lambda_max / lambda_min: power iteration on A and inverse iteration
+ * with A's Cholesky factor, on the device (up to 3m = 1024 rows; within a few per cent, never above
+ * the true value; beyond 1024 rows the pivot bound (max L_ii / min L_ii)^2, a lower bound) -- +inf
+ * when A is not positive definite.  The caller compares with kGoodConditionNumber = 1e7
+ * (constants.h:12) and picks the cfm of the step, as ensembles.cc:513-521.                      */
 egs_status egs_problem_dense_condition(egs_problem *p, double cfm, double *estimate);
+/* The same for a caller's own symmetric positive definite matrix (A [N][N] row-major, host): replaces
+ * GetConditionNumber(A) / CheckMatrixCondition(A) of utils.cc:256-287 as such.  *pivot_bound (may be
+ * NULL) receives the cheap lower bound (max L_ii / min L_ii)^2 beside the estimate.               */
+egs_status egs_dense_condition(egs_context *ctx, int32_t N, const double *A, double *estimate, double *pivot_bound);
 /* One StepVelocities_ODE through the reference's LIVE dense path (ensembles.cc:563-575,
  * 498-538): assemble, dense system with the cfm the caller decided, then
  * Lcp::MixedConstraintsSolver on the device matrix (use_bounds as in entry 3), v update.

@@ -12,7 +12,8 @@ import bench  # noqa: E402
 from eggshell_amd import capi  # noqa: E402
 
 ctx = capi.Context(0)
-for N, mode in ((2048, 2), (512, 2), (512, 0)):
+cases = ((2048, 2), (512, 2), (512, 0)) if len(sys.argv) < 2 else ((int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 2),)
+for N, mode in cases:
     A, b, C, lo, hi = bench.c5_problem(N)
     ctx.mixed_constraints_solve(A, b, C, lo, hi, use_bounds=mode)
     best = 1e9
