@@ -226,6 +226,8 @@ struct egs_problem {
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
   DevBuf<GlobalDesc> gcons;
   DevBuf<uint32_t> gtickets;
+  DevBuf<unsigned char> ggran;   // [n][6] x 16 B: data-tagged granules of the 4-lane body patches (quad_solve.hip)
+  uint32_t gran_epoch = 0;
   // oversize islands as body patches (GS/SOR): LDS for private bodies, global for shared
   DevBuf<LaneDesc> p_lanes;
   DevBuf<int32_t> p_tile_nslots, p_tile_slot_off, p_slot_body;
@@ -483,6 +485,23 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       a.hist_acc = reinterpret_cast<REAL *>(p->hist_acc.p);
     }
     if (p->oversize == kQuadPatches) {
+      {   // hand-offs between patches as data-tagged granules (EGS_GRANULES=0: payload + flag, the round-2 protocol)
+        const char *ge = std::getenv("EGS_GRANULES");
+        if (!(ge && std::atoi(ge) == 0)) {
+          const size_t bytes = (size_t)(p->n > 0 ? p->n : 1) * 6 * 16;
+          if (p->ggran.cap < bytes) {
+            p->ggran.alloc(bytes);
+            HIPCHK(hipMemsetAsync(p->ggran.p, 0, bytes, ctx->stream));
+            p->gran_epoch = 0;
+          }
+          if (++p->gran_epoch == 0) {     // the epoch wrapped: old tags could match again
+            HIPCHK(hipMemsetAsync(p->ggran.p, 0, bytes, ctx->stream));
+            p->gran_epoch = 1;
+          }
+          a.gran = p->ggran.p;
+          a.gran_epoch = p->gran_epoch;
+        }
+      }
       // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
       a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);

@@ -46,6 +46,10 @@ struct SolveArgs {
   REAL *hist_x = nullptr;      // [sweeps][m][3]
   REAL *hist_acc = nullptr;    // [sweeps][n_bodies][6]
   int32_t n_bodies = 0;
+  // body patches on the 4-lane kernel: a shared body's accumulator crosses between patches as six data-tagged
+  // 16-byte granules {value, launch epoch << 32 | ticket} (quad_solve.hip); NULL = the flag protocol (g_tick)
+  void *gran = nullptr;        // [n_bodies][6] x 16 B
+  uint32_t gran_epoch = 0;
 };
 
 template <typename REAL>

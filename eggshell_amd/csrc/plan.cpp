@@ -141,6 +141,19 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     d.pos1 = (uint16_t)pos1[c]; d.cnt1 = (uint16_t)(body1[c] >= 0 ? cnt[body1[c]] : 0);
     plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
   }
+  // Lanes that wait on ANOTHER patch (a side whose list-order neighbour is remote) poll global memory: a look costs a
+  // memory round trip (~1-2 us) and stalls the whole wavefront, i.e. every constraint that shares it, including those
+  // whose hand-offs are LDS-local (0.2-0.4 us).  So the patch's boundary constraints go to the front -- into as few
+  // wavefronts as possible -- and the interior ones keep wavefronts of their own that never leave LDS.  The tickets
+  // keep the list order whatever the lane order is (same bits; EGS_PATCH_ORDER=0 keeps list order for comparison).
+  {
+    const char *e = std::getenv("EGS_PATCH_ORDER");
+    if (!(e && std::atoi(e) == 0)) {
+      auto boundary = [](const LaneDesc &d) { return ((d.slot0 | d.slot1) & (kPrevRemote | kNextRemote)) != 0; };
+      for (int t = 0; t < np; ++t)
+        std::stable_partition(plan.patch_lanes.begin() + (size_t)t * block, plan.patch_lanes.begin() + (size_t)t * block + fill[t], boundary);
+    }
+  }
   if (overflow) {   // cannot happen with <= 512 sides per patch; keep the all-global path if it ever does
     plan.n_patch_tiles = 0; plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear();
     return;

@@ -85,6 +85,51 @@ __device__ __forceinline__ void store3(unsigned acc_addr, const float (&a)[3]) {
       : "memory");
 }
 
+// ---- data-tagged granules: the hand-off between body patches ----------------------------------
+// A shared body's accumulator used to cross patches as payload + flag: sc1 stores -> s_waitcnt vmcnt(0) -> sc1 ticket
+// store on one side, ticket poll -> payload loads on the other: two dependent round trips through the memory side on
+// each side (MI355X_MICROARCH.md price list, handoff-flag: 1.3 us idle, 3.8-4.9 under load; ~4 us measured here).
+// Now every component travels as ONE naturally aligned 16-byte granule {value, tag}, tag = launch epoch << 32 | the
+// body's ticket AFTER the update, written by one global_store_dwordx4 sc1 and read by one global_load_dwordx4 sc1
+// (observed untorn on gfx950 / ROCm 7.2): the producer neither waits for its stores nor writes a flag, the consumer's
+// poll IS the payload load (handoff-1to1: 0.8-1.0 us idle).  A body's six granules share one 96-byte stretch laid out
+// [component][half], so that the two lanes of a side read / write 32 contiguous bytes per instruction.  Tickets only
+// grow within a launch and the epoch separates launches, so a matching tag can only be the predecessor's store.
+typedef unsigned gran_u4 __attribute__((ext_vector_type(4)));
+struct alignas(16) Gran { unsigned long long bits, tag; };
+
+template <typename REAL> __device__ __forceinline__ unsigned long long gran_bits(REAL v);
+template <> __device__ __forceinline__ unsigned long long gran_bits<double>(double v) { return (unsigned long long)__double_as_longlong(v); }
+template <> __device__ __forceinline__ unsigned long long gran_bits<float>(float v) { return (unsigned long long)__float_as_uint(v); }
+template <typename REAL> __device__ __forceinline__ REAL gran_value(unsigned lo, unsigned hi);
+template <> __device__ __forceinline__ double gran_value<double>(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+template <> __device__ __forceinline__ float gran_value<float>(unsigned lo, unsigned) { return __uint_as_float(lo); }
+
+// this lane's three granules (stride 2: the other half's sit in between), no wait, no flag
+template <typename REAL>
+__device__ __forceinline__ void gran_store3(Gran *p, const REAL (&a)[3], unsigned long long tag) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long b = gran_bits<REAL>(a[k]);
+    const gran_u4 v = {(unsigned)b, (unsigned)(b >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p + 2 * k), "v"(v) : "memory");
+  }
+}
+// one look: three loads in flight, one wait; true (and the values) iff all three carry `tag`
+template <typename REAL>
+__device__ __forceinline__ bool gran_poll3(const Gran *p, unsigned long long tag, REAL (&a)[3]) {
+  gran_u4 g0, g1, g2;
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off sc1\n\t"
+      "global_load_dwordx4 %1, %3, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %2, %3, off offset:64 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(g0), "=&v"(g1), "=&v"(g2) : "v"(p) : "memory");
+  const unsigned tl = (unsigned)tag, th = (unsigned)(tag >> 32);
+  a[0] = gran_value<REAL>(g0.x, g0.y); a[1] = gran_value<REAL>(g1.x, g1.y); a[2] = gran_value<REAL>(g2.x, g2.y);
+  return g0.z == tl && g0.w == th && g1.z == tl && g1.w == th && g2.z == tl && g2.w == th;
+}
+
 // QT = constraints per tile; the workgroup has 4 * QT threads (64 -> 256, 256 -> 1024).
 // PATCH = true: the tile is a body patch of an island larger than a workgroup
 // (plan.cpp::build_patches).  A body that other workgroups touch too has an LDS slot
@@ -129,10 +174,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   unsigned *my_tick = s_tick + slot;
   REAL *g_acc = A.acc;
   uint32_t *g_t = g_tick;
+  Gran *my_gran = nullptr;
+  const bool gran = PATCH && A.gran != nullptr;      // uniform
+  const unsigned long long epoch_hi = (unsigned long long)A.gran_epoch << 32;
   if (sh) {   // where the accumulator crosses between patches
     const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
     g_acc = A.acc + (size_t)body * 6 + 3 * half;
     g_t = g_tick + body;
+    my_gran = reinterpret_cast<Gran *>(A.gran) + (size_t)body * 6 + half;     // [component][half]
   }
 
   REAL Jh[9], Bh[9], Dl[3], inv[3], rhs[3], lo[3], hi[3], x[3];
@@ -179,11 +228,21 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     // (pos 0: both places hold zeros) and goes there if the successor is
     // (a launch without sweeps ends here: then the body's last update goes to global memory)
     const bool acq = prev_remote, rel = next_remote || (sh && A.sweeps == 0 && pos == cnt - 1u);
+    // granules: the body's first update starts from zero (nobody wrote before it); a launch without sweeps leaves the
+    // last value in A.acc, where the next launch and the follow-up kernels look for it
+    const bool acq_g = gran && acq && pos != 0u, end_g = gran && sh && A.sweeps == 0 && pos == cnt - 1u;
     while (pending) {
-      const unsigned t = acq ? gld(g_t) : lds_load_acquire(my_tick);
+      REAL ga[3] = {REAL(0), REAL(0), REAL(0)};
+      unsigned t;
+      if (acq_g) t = gran_poll3<REAL>(my_gran, epoch_hi | pos, ga) ? pos : pos + 1u;
+      else if (gran && acq) t = pos;
+      else t = acq ? gld(g_t) : lds_load_acquire(my_tick);
       if (t == pos) {
         REAL a[3];
-        if (acq) {
+        if (gran && acq) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a[k] = ga[k];
+        } else if (acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
@@ -197,7 +256,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
           u = tfma(Bh[3 * k + 1], x[1], u);
           a[k] = tfma(Bh[3 * k + 2], x[2], u);
         }
-        if (rel) {
+        if (gran && rel) {
+          if (end_g) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gst(g_acc + k, a[k]);
+          } else {
+            gran_store3<REAL>(my_gran, a, epoch_hi | (pos + 1u));
+          }
+        } else if (rel) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) gst(g_acc + k, a[k]);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -231,17 +297,26 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       REAL a[3];
       // a shared body's first update of a resumed launch reads global memory, its last update of
       // the launch writes it (the accumulator must not stay behind in some patch's LDS)
-      const bool acq = acq_side || (sh && A.resume && sweep == 1 && ord == 0u);
-      const bool rel = rel_side || (sh && sweep == A.sweeps && ord == cnt - 1u);
+      const bool first_of_launch = sh && A.resume && sweep == 1 && ord == 0u;
+      const bool last_of_launch = sh && sweep == A.sweeps && ord == cnt - 1u;
+      const bool acq = acq_side || first_of_launch;
+      const bool rel = rel_side || last_of_launch;
+      // granules: a predecessor in another patch of THIS launch is polled for; at the launch boundary the value is in A.acc
+      const bool acq_g = gran && acq_side && !first_of_launch;
+      REAL ga[3] = {REAL(0), REAL(0), REAL(0)};
       unsigned gt = want;
-      if (acq) gt = gld(g_t);
+      if (acq_g) gt = gran_poll3<REAL>(my_gran, epoch_hi | want, ga) ? want : want + 1u;
+      else if (acq && !gran) gt = gld(g_t);
       poll3(tick_addr, acc_addr, t, a);
       if (acq) t = gt;
       int rdy = (!has || t == want) ? 1 : 0;
       rdy &= dpp_i<kXor1>(rdy);
       rdy &= dpp_i<kXor2>(rdy);
       if (rdy) {
-        if (acq) {
+        if (acq_g) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a[k] = ga[k];
+        } else if (acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
@@ -288,7 +363,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             an[k] = tfma(Bh[3 * k + 2], dx[2], u);
             an_hist[k] = an[k];
           }
-          if (rel) {
+          if (gran && rel) {
+            if (last_of_launch) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
+            } else {
+              gran_store3<REAL>(my_gran, an, epoch_hi | (want + 1u));
+            }
+          } else if (rel) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
