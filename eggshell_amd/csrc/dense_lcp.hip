@@ -140,35 +140,45 @@ __global__ void __launch_bounds__(320) chol_diag_kernel(double *T, int ld, int k
   }
 }
 
-// Panel below the diagonal block: X = B L11^-T = B (L11^-1)^T on the fp64 matrix
-// cores, X[r][c] = sum_k B[r][k] Linv[c][k].  One workgroup per 64-row slab,
-// each wavefront a 32x32 quadrant (operand maps as in chol_update_kernel).
-__global__ void __launch_bounds__(256) chol_trsm_kernel(double *T, int ld, int nrows, int k0, const double *inv) {
-  const int r0 = k0 + NB + blockIdx.x * NB;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int qr = r0 + (wave >> 1) * 32, qc = (wave & 1) * 32;
-  const int li = lane & 15, lk = lane >> 4;
-  double4_t acc[2][2];
+// A 64 x 64 block of doubles from global memory (row stride ld) into LDS (row stride kStageLd) with 16-byte loads, all
+// of a thread's eight loads in flight at once: one memory round trip per operand instead of one per k-step of the MFMA
+// loop.  Rows at or beyond `nrows` read as zero.  Threads 0..255: thread t takes row t / 4, columns 16 (t % 4) .. + 15.
+constexpr int kStageLd = NB + 2;     // doubles; keeps 16-byte alignment of every row start
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void stage_block(const double *src, int ld, int row0, int nrows, double *dst) {
+  if (threadIdx.x >= 256) return;
+  const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 16;
+  const bool ok = row0 + r < nrows;
+  const double *p = src + (size_t)(ok ? row0 + r : 0) * ld + c;
+  double v[16];
+  if ((((size_t)p) & 15) == 0) {
+    double2_t q[8];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int k = 0; k < 8; ++k) q[k] = ok ? *reinterpret_cast<const double2_t *>(p + 2 * k) : (double2_t){0.0, 0.0};
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const double *Pa[2], *Pb[2];
-  bool va[2];
+    for (int k = 0; k < 8; ++k) { v[2 * k] = q[k].x; v[2 * k + 1] = q[k].y; }
+  } else {          // an odd leading dimension leaves rows 8-byte aligned only
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ra = qr + 16 * t + li;
-    va[t] = ra < nrows;
-    Pa[t] = T + (size_t)(va[t] ? ra : 0) * ld + k0;
-    Pb[t] = inv + (size_t)(qc + 16 * t + li) * NB;
+    for (int k = 0; k < 16; ++k) v[k] = ok ? p[k] : 0.0;
   }
+  double *d = dst + r * kStageLd + c;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) *reinterpret_cast<double2_t *>(d + 2 * k) = (double2_t){v[2 * k], v[2 * k + 1]};
+}
+
+// acc[ti][tj] += (rows lr.. of sA) (rows lc.. of sB)^T over K = 64: the 32 x 32 quadrant of one wavefront.
+// v_mfma_f64_16x16x4_f64 operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+__device__ __forceinline__ void mfma_quadrant(const double *sA, const double *sB, int lr, int lc, double4_t (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
     double a[2], b[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = va[t] ? Pa[t][4 * kk + lk] : 0.0;
-      b[t] = Pb[t][4 * kk + lk];
+      a[t] = sA[(lr + 16 * t + li) * kStageLd + 4 * kk + lk];
+      b[t] = sB[(lc + 16 * t + li) * kStageLd + 4 * kk + lk];
     }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -176,30 +186,50 @@ __global__ void __launch_bounds__(256) chol_trsm_kernel(double *T, int ld, int n
       for (int tj = 0; tj < 2; ++tj)
         acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
   }
-  __syncthreads();   // every wavefront has read its rows of B before anyone overwrites them
+}
+
+// Panel below the diagonal block: X = B L11^-T = B (L11^-1)^T on the fp64 matrix
+// cores, X[r][c] = sum_k B[r][k] Linv[c][k].  One workgroup per 64-row slab,
+// each wavefront a 32x32 quadrant; both operands staged in LDS.  B is read from T, X goes to Tout (may be T).
+__global__ void __launch_bounds__(256) chol_trsm_kernel(const double *T, double *Tout, int ld, int nrows, int k0, const double *inv) {
+  __shared__ __attribute__((aligned(16))) double sA[NB * kStageLd], sBm[NB * kStageLd];
+  const int r0 = k0 + NB + blockIdx.x * NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = (wave >> 1) * 32, lc = (wave & 1) * 32;
+  const int li = lane & 15, lk = lane >> 4;
+  stage_block(T + k0, ld, r0, nrows, sA);
+  stage_block(inv, NB, 0, NB, sBm);
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
+  mfma_quadrant(sA, sBm, lr, lc, acc);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
-        if (r < nrows) T[(size_t)r * ld + k0 + c] = acc[ti][tj][reg];
+        const int r = r0 + lr + 16 * ti + lk + 4 * reg, c = lc + 16 * tj + li;
+        if (r < nrows) Tout[(size_t)r * ld + k0 + c] = acc[ti][tj][reg];
       }
 }
 
 // Trailing update on the fp64 matrix cores: for rows r >= k0+64 and columns
 // c in [k0+64, ld) with c <= r (lower trapezoid),  T[r][c] -= sum_k P[r][k] P[c][k],
 // P = T[:, k0..k0+64).  One workgroup (4 wavefronts) per 64x64 tile; each
-// wavefront owns a 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps of 4.
-// v_mfma_f64_16x16x4_f64 operand maps: A[i = lane&15][k = lane>>4],
-// B[k = lane>>4][j = lane&15]; D: col = lane&15, row = (lane>>4) + 4*reg.
+// wavefront owns a 32x32 quadrant = 2x2 MFMA tiles, K = 64 in 16 steps of 4; the two 64 x 64 pieces of the panel are
+// staged in LDS first (stage_block).
 __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int nrows, int k0) {
+  __shared__ __attribute__((aligned(16))) double sA[NB * kStageLd], sBm[NB * kStageLd];
   const int r0 = k0 + NB + blockIdx.y * NB;
   const int c0 = k0 + NB + blockIdx.x * NB;
   if (c0 > r0 + NB - 1) return;  // tile entirely above the diagonal
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int qr = r0 + (wave >> 1) * 32, qc = c0 + (wave & 1) * 32;
+  const int lr = (wave >> 1) * 32, lc = (wave & 1) * 32;
+  const int qr = r0 + lr, qc = c0 + lc;
   const int li = lane & 15, lk = lane >> 4;
   double4_t acc[2][2], told[2][2];
 #pragma unroll
@@ -216,29 +246,11 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
         const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
         told[ti][tj][reg] = (r < nrows && c < ld && c <= r) ? T[(size_t)r * ld + c] : 0.0;
       }
-  const double *Pa[2], *Pb[2];
-  bool va[2], vb[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ra = qr + 16 * t + li, rb = qc + 16 * t + li;
-    va[t] = ra < nrows; vb[t] = rb < nrows && rb < ld;
-    Pa[t] = T + (size_t)(va[t] ? ra : 0) * ld + k0;
-    Pb[t] = T + (size_t)(vb[t] ? rb : 0) * ld + k0;
-  }
-#pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    double a[2], b[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      a[t] = va[t] ? Pa[t][4 * kk + lk] : 0.0;
-      b[t] = vb[t] ? Pb[t][4 * kk + lk] : 0.0;
-    }
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
-  }
+  const bool diag = r0 == c0;
+  stage_block(T + k0, ld, r0, nrows, sA);
+  if (!diag) stage_block(T + k0, ld, c0, nrows < ld ? nrows : ld, sBm);     // rows of the panel that are columns of the tile
+  __syncthreads();
+  mfma_quadrant(sA, diag ? sA : sBm, lr, lc, acc);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -713,7 +725,7 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, doub
     double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, ld, k0, inv_k, fail);
     const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
-    if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, ld, nrows, k0, inv_k);
+    if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, T, ld, nrows, k0, inv_k);
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
     if (tr > 0 && tc > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tc, tr), dim3(256), 0, s, T, ld, nrows, k0);
   }

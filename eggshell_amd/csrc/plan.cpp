@@ -149,9 +149,15 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
   {
     const char *e = std::getenv("EGS_PATCH_ORDER");
     if (!(e && std::atoi(e) == 0)) {
-      auto boundary = [](const LaneDesc &d) { return ((d.slot0 | d.slot1) & (kPrevRemote | kNextRemote)) != 0; };
+      // (three groups: lanes that wait on another patch in a forward sweep -- a remote predecessor --, lanes that only do
+      //  so in a backward sweep, interior lanes: the first group alone polls global memory under Gauss-Seidel)
+      auto group = [](const LaneDesc &d) {
+        const int f = d.slot0 | d.slot1;
+        return (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : 2;
+      };
       for (int t = 0; t < np; ++t)
-        std::stable_partition(plan.patch_lanes.begin() + (size_t)t * block, plan.patch_lanes.begin() + (size_t)t * block + fill[t], boundary);
+        std::stable_sort(plan.patch_lanes.begin() + (size_t)t * block, plan.patch_lanes.begin() + (size_t)t * block + fill[t],
+                         [&](const LaneDesc &a, const LaneDesc &b) { return group(a) < group(b); });
     }
   }
   if (overflow) {   // cannot happen with <= 512 sides per patch; keep the all-global path if it ever does
