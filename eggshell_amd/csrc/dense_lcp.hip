@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -89,7 +90,7 @@ __device__ __forceinline__ void lds_barrier() {
 //     by those columns (row j of the inverse is complete after step j).
 // The inverse turns the panel's triangular solve and the diagonal steps of the
 // back substitution into matrix products (chol_trsm_kernel, back_solve_kernel).
-__global__ void __launch_bounds__(320) chol_diag_kernel(double *T, int ld, int k0, double *inv, int *fail) {
+__global__ void __launch_bounds__(320) chol_diag_kernel(const double *T, double *Tout, int ld, int k0, double *inv, int *fail) {
   __shared__ __attribute__((aligned(16))) double sCol[2][NB];
   __shared__ double sRinv[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(320) chol_diag_kernel(double *T, int ld, int k
         const double l = (lane >= j) ? a[mo] * rinv : 0.0;
         sCol[j & 1][lane] = l;
         if (lane == j) sRinv[j & 1] = rinv;
-        if (lane >= j) T[(size_t)(k0 + lane) * ld + k0 + j] = l;
+        if (lane >= j) Tout[(size_t)(k0 + lane) * ld + k0 + j] = l;
       }
       lds_barrier();
       if (j + 1 < NB) {
@@ -704,11 +705,48 @@ __global__ void __launch_bounds__(256) murty_small_kernel(int n, const double *A
   if (tid == 0) { res->solved = solved; res->pivots = pivots; res->not_spd = s_fail; res->pad = 0; }
 }
 
+// Device scratch of the dense solvers.  A solve takes some twenty-five buffers; hipMalloc + hipFree for each of them
+// (hipFree synchronises the device) cost more than a millisecond per call at N = 2048.  Freed blocks therefore go to a
+// small per-host-thread cache and the next request of at most that size reuses them; the cache holds at most 256 MB
+// (beyond that a released block is really freed).
+struct ScratchCache {
+  struct Block { void *p; size_t bytes; };
+  std::vector<Block> free_blocks;
+  size_t held = 0;
+  ~ScratchCache() { for (auto &b : free_blocks) (void)hipFree(b.p); }
+  void *take(size_t &bytes) {      // in: wanted, out: the block's real size
+    int best = -1;
+    for (int i = 0; i < (int)free_blocks.size(); ++i)
+      if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 && (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+    if (best >= 0) {
+      void *p = free_blocks[best].p;
+      bytes = free_blocks[best].bytes;
+      held -= bytes;
+      free_blocks.erase(free_blocks.begin() + best);
+      return p;
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    return p;
+  }
+  void give(void *p, size_t bytes) {
+    if (held + bytes > (size_t(256) << 20)) { (void)hipFree(p); return; }
+    free_blocks.push_back({p, bytes});
+    held += bytes;
+  }
+};
+thread_local ScratchCache g_scratch;
+
 template <typename T>
 struct Buf {
   T *p = nullptr;
-  explicit Buf(size_t n) { if (n) HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T))); }
-  ~Buf() { if (p) (void)hipFree(p); }
+  size_t bytes = 0;
+  explicit Buf(size_t n) {
+    if (n) { bytes = ((n * sizeof(T) + 255) / 256) * 256; p = static_cast<T *>(g_scratch.take(bytes)); }
+  }
+  // a block goes back to the cache while kernels that use it may still be queued: the next user enqueues on the same
+  // stream (one context = one stream = one host thread), so the stream's order keeps them apart
+  ~Buf() { if (p) g_scratch.give(p, bytes); }
   Buf(const Buf &) = delete;
   Buf &operator=(const Buf &) = delete;
 };
@@ -718,17 +756,223 @@ inline int grid1(size_t n, int block = 256) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// ---- one launch per panel -------------------------------------------------------------------------------
+// The three launches of a panel step (diagonal block -> panel solve -> trailing update) run one after the other and
+// the first, a 64-column latency chain in ONE workgroup, takes 20 of the 37 us.  chol_panel_kernel does the panel
+// solve AND the trailing update of panel k in one launch, and the workgroup that finishes the NEXT diagonal tile
+// factors it on the spot (chol_diag_tile, the algorithm of chol_diag_kernel on a tile staged in LDS), while the other
+// workgroups are still updating: per panel one launch whose length is that one workgroup's (update + 20 us).
+//   * Every workgroup needs X_r = B_r L^-T and X_c = B_c L^-T of its tile's row blocks; it computes them itself from the
+//     unsolved panel (two extra 64^3 MFMA products per tile: the matrix cores are idle anyway) instead of waiting for a
+//     panel-solve launch.
+//   * Nobody may overwrite the panel while others still read it, so the solved panel X, the factored diagonal blocks
+//     and nothing else go to a second array (Tl, same shape); T keeps taking the trailing updates.  After the last panel
+//     merge_factor_kernel copies the factored columns back, so every consumer finds L where it always was.
+constexpr int kPanelThreads = 320;     // four MFMA wavefronts + the inverse wavefront of the diagonal tile
+
+// chol_diag_kernel's algorithm on a tile staged in LDS (sB, row-major, stride kStageLd): L goes to Tout, the inverse to inv
+__device__ void chol_diag_tile(const double *sB, double (*sCol)[NB], double *sRinv, double *Tout, int ld, int k0, double *inv, int *fail) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < 4) {
+    double a[NB / 4];
+#pragma unroll
+    for (int m = 0; m < NB / 4; ++m) {
+      const int c = 4 * m + wave;
+      a[m] = (c <= lane) ? sB[lane * kStageLd + c] : 0.0;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int mo = j >> 2;
+      if (wave == (j & 3)) {
+        double d = readlane_f64(a[mo], j);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double rinv = rsqrt_refined(d);
+        const double l = (lane >= j) ? a[mo] * rinv : 0.0;
+        sCol[j & 1][lane] = l;
+        if (lane == j) sRinv[j & 1] = rinv;
+        if (lane >= j) Tout[(size_t)(k0 + lane) * ld + k0 + j] = l;
+      }
+      lds_barrier();
+      if (j + 1 < NB) {
+        const double lrow = sCol[j & 1][lane];
+#pragma unroll
+        for (int m = mo; m < NB / 4; ++m) a[m] = __builtin_fma(-lrow, sCol[j & 1][4 * m + wave], a[m]);
+      }
+    }
+    if (bad && lane == 0) atomicOr(fail, 1);
+  } else {
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      lds_barrier();
+      const double xj = (((lane == j) ? 1.0 : 0.0) - a[j]) * sRinv[j & 1];
+      inv[j * NB + lane] = xj;
+      double col[NB];
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(col[k], xj, a[k]);
+    }
+  }
+}
+
+// grid (tc, tr) over the 64 x 64 tiles of the trailing trapezoid of panel k0 (as chol_update_kernel).
+// factor_next: the tile (k0 + 64, k0 + 64) is the next diagonal block to factor (k0 + 64 < nf).
+__global__ void __launch_bounds__(kPanelThreads) chol_panel_kernel(double *T, double *Tl, int ld, int nrows, int k0, const double *inv_k,
+                                                                   double *inv_next, int *fail, int factor_next) {
+  extern __shared__ __attribute__((aligned(16))) double smem_d[];
+  double *sA = smem_d, *sBm = sA + NB * kStageLd, *sI = sBm + NB * kStageLd;
+  double (*sCol)[NB] = reinterpret_cast<double (*)[NB]>(sI + NB * kStageLd);
+  double *sRinv = &sCol[2][0];
+  const int r0 = k0 + NB + blockIdx.y * NB;
+  const int c0 = k0 + NB + blockIdx.x * NB;
+  if (c0 > r0 + NB - 1) return;  // tile entirely above the diagonal
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool mm = wave < 4;      // the MFMA wavefronts
+  const int lr = (wave >> 1) * 32, lc = (wave & 1) * 32;
+  const int qr = r0 + lr, qc = c0 + lc;
+  const int li = lane & 15, lk = lane >> 4;
+  const bool diag = r0 == c0;
+  double4_t told[2][2], xr[2][2], xc[2][2], acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      xr[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0}; xc[a][b] = xr[a][b]; acc[a][b] = xr[a][b]; told[a][b] = xr[a][b];
+    }
+  if (mm) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
+          told[ti][tj][reg] = (r < nrows && c < ld && c <= r) ? T[(size_t)r * ld + c] : 0.0;
+        }
+  }
+  stage_block(T + k0, ld, r0, nrows, sA);
+  if (!diag) stage_block(T + k0, ld, c0, nrows < ld ? nrows : ld, sBm);
+  stage_block(inv_k, NB, 0, NB, sI);
+  __syncthreads();
+  // the solved panel rows of this tile: X = B L^-T, X[r][c] = sum_k B[r][k] Linv[c][k]
+  if (mm) {
+    mfma_quadrant(sA, sI, lr, lc, xr);
+    if (!diag) mfma_quadrant(sBm, sI, lr, lc, xc);
+  }
+  __syncthreads();
+  if (mm) {
+    // back into LDS as operands of the update; the first tile of every row block also files its X rows in Tl
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rr = lr + 16 * ti + lk + 4 * reg, cc = lc + 16 * tj + li;
+          sA[rr * kStageLd + cc] = xr[ti][tj][reg];
+          if (!diag) sBm[rr * kStageLd + cc] = xc[ti][tj][reg];
+          if (blockIdx.x == 0 && r0 + rr < nrows) Tl[(size_t)(r0 + rr) * ld + k0 + cc] = xr[ti][tj][reg];
+        }
+  }
+  __syncthreads();
+  if (mm) mfma_quadrant(sA, diag ? sA : sBm, lr, lc, acc);
+  const bool factor_here = factor_next && diag && blockIdx.x == 0;      // uniform
+  if (!factor_here) {
+    if (mm) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int r = qr + 16 * ti + lk + 4 * reg, c = qc + 16 * tj + li;
+            if (r < nrows && c < ld && c <= r) T[(size_t)r * ld + c] = told[ti][tj][reg] - acc[ti][tj][reg];
+          }
+    }
+    return;
+  }
+  // the next diagonal block: updated tile -> LDS -> L and its inverse
+  __syncthreads();
+  if (mm) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rr = lr + 16 * ti + lk + 4 * reg, cc = lc + 16 * tj + li;
+          sBm[rr * kStageLd + cc] = told[ti][tj][reg] - acc[ti][tj][reg];
+        }
+  }
+  __syncthreads();
+  chol_diag_tile(sBm, sCol, sRinv, Tl, ld, r0, inv_next, fail);
+}
+
+// the factored columns (and the solved rows below them) back from Tl into T
+__global__ void merge_factor_kernel(double *T, const double *Tl, int ld, int nrows, int nf) {
+  const size_t total = (size_t)nrows * nf;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / nf), c = (int)(idx % nf);
+    if (r >= c) T[(size_t)r * ld + c] = Tl[(size_t)r * ld + c];
+  }
+}
+
+// work area of the factorisation (the second array), kept per host thread, grow-only
+struct FactorWork {
+  double *p = nullptr;
+  size_t cap = 0;
+};
+thread_local FactorWork g_fwork;
+
 // Blocked Cholesky of the first nf (multiple of 64) columns of T; inv receives
 // the nf/64 inverted diagonal blocks (64x64 each).
-void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
+void factor_launches(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
   for (int k0 = 0; k0 < nf; k0 += NB) {
     double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, ld, k0, inv_k, fail);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, T, ld, k0, inv_k, fail);
     const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
     if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, T, ld, nrows, k0, inv_k);
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
     if (tr > 0 && tc > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tc, tr), dim3(256), 0, s, T, ld, nrows, k0);
   }
+}
+
+void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
+  if (nf <= 0) return;
+  static const bool fused = [] { const char *e = std::getenv("EGS_CHOL_FUSED"); return !(e && std::atoi(e) == 0); }();
+  if (!fused || nf <= NB) { factor_launches(s, T, ld, nrows, nf, fail, inv); return; }
+  const size_t need = (size_t)nrows * ld;
+  if (g_fwork.cap < need) {
+    if (g_fwork.p) { HIPCHK(hipStreamSynchronize(s)); (void)hipFree(g_fwork.p); g_fwork.p = nullptr; g_fwork.cap = 0; }
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&g_fwork.p), (need + need / 4) * sizeof(double)));
+    g_fwork.cap = need + need / 4;
+  }
+  double *Tl = g_fwork.p;
+  const size_t lds = (size_t)(3 * NB * kStageLd + 3 * NB) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // the first diagonal block has no update before it
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, Tl, ld, 0, inv, fail);
+  for (int k0 = 0; k0 < nf; k0 += NB) {
+    double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
+    const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
+    if (tr > 0 && tc > 0) {
+      const int factor_next = (k0 + NB < nf) ? 1 : 0;
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(tc, tr), dim3(kPanelThreads), lds, s, T, Tl, ld, nrows, k0, inv_k, inv_k + NB * NB, fail, factor_next);
+    } else {
+      // nothing to the right of this panel: only the rows below it are left to solve (k0 + 64 == nf here)
+      const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
+      if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, Tl, ld, nrows, k0, inv_k);
+    }
+  }
+  hipLaunchKernelGGL(merge_factor_kernel, dim3(grid1((size_t)nrows * nf)), dim3(256), 0, s, T, Tl, ld, nrows, nf);
 }
 
 // Murty on (A n x n device, b device).  Mirrors lcp.cc:157-274; box_fix as in
@@ -792,9 +1036,14 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     HIPCHK(hipMemcpyAsync(S_d.p, S.data(), n, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(Cb.p, Cv.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
   };
+  std::vector<double> xh(n), wh(n);
   auto check = [&](const double *xx, const double *ww, const double *rr, MurtyRecord *out) {
     hipLaunchKernelGGL(murty_check_kernel, dim3(1), dim3(1024), 0, s, n, xx, ww, rr, S_d.p, Cb.p, lo_d.p, hi_d.p, rec_d.p);
     HIPCHK(hipMemcpyAsync(out, rec_d.p, sizeof(MurtyRecord), hipMemcpyDeviceToHost, s));
+    if (block) {   // the block rule looks at every x and w: they ride on the same synchronisation as the record
+      HIPCHK(hipMemcpyAsync(xh.data(), xx, n * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(wh.data(), ww, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
   };
   auto is_solution = [&](const MurtyRecord &rc, double tol) {
@@ -807,7 +1056,6 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   };
   upload_state();
   MurtyRecord rc;
-  std::vector<double> xh(n), wh(n);
   int iter = 0, pivots = 0;
   int best_ninf = n + 1, patience = 10;   // block rule state
   bool force = box_fix, solved = false;
@@ -827,10 +1075,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
         // no index to flip but not a solution (residual / sign checks failed):
         // the reference recomputes with unchanged S; do the same.
       } else if (block) {
-        HIPCHK(hipMemcpyAsync(xh.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(wh.data(), dw, n * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        std::vector<int> bad;
+        std::vector<int> bad;      // xh, wh came with the record (check)
         for (int i = 0; i < n; ++i) {
           const bool off = S[i] ? (xh[i] < lo[i] || xh[i] > hi[i])
                                 : ((Cv[i] == lo[i] && wh[i] < 0) || (Cv[i] == hi[i] && wh[i] > 0));
