@@ -36,6 +36,9 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
                    const std::vector<int32_t> &pos1) {
   const int block = plan.block;
   const int mg = (int)plan.global.size();
+  // head-room for the idle lanes that align the lane groups to wavefronts (below)
+  const bool order_groups = [] { const char *e = std::getenv("EGS_PATCH_ORDER"); return !(e && std::atoi(e) == 0); }();
+  const int cap = (order_groups && block >= 128) ? block - 32 : block;
   // owner body of a constraint = its first real body
   auto owner = [&](int c) { return body0[c] >= 0 ? body0[c] : body1[c]; };
   std::vector<int32_t> owned(n_bodies, 0);
@@ -62,7 +65,7 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     for (size_t qh = 0; qh < queue.size(); ++qh) {
       const int b = queue[qh];
       if (patch_of[b] >= 0) continue;
-      if (patch_fill[pid] + owned[b] > block) continue;   // does not fit: left for a later patch
+      if (patch_fill[pid] + owned[b] > (owned[b] > cap ? block : cap)) continue;   // does not fit: left for a later patch
       patch_of[b] = pid;
       patch_fill[pid] += owned[b];
       for (int g : touch[b]) {
@@ -70,7 +73,7 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
         for (int nb : {body0[c], body1[c]})
           if (nb >= 0 && patch_of[nb] < 0) queue.push_back(nb);
       }
-      if (patch_fill[pid] == block) break;
+      if (patch_fill[pid] >= cap) break;
     }
   }
   // drop empty patches (bodies that own nothing) by renumbering patches with constraints
@@ -146,18 +149,32 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
   // whose hand-offs are LDS-local (0.2-0.4 us).  So the patch's boundary constraints go to the front -- into as few
   // wavefronts as possible -- and the interior ones keep wavefronts of their own that never leave LDS.  The tickets
   // keep the list order whatever the lane order is (same bits; EGS_PATCH_ORDER=0 keeps list order for comparison).
-  {
-    const char *e = std::getenv("EGS_PATCH_ORDER");
-    if (!(e && std::atoi(e) == 0)) {
-      // (three groups: lanes that wait on another patch in a forward sweep -- a remote predecessor --, lanes that only do
-      //  so in a backward sweep, interior lanes: the first group alone polls global memory under Gauss-Seidel)
-      auto group = [](const LaneDesc &d) {
-        const int f = d.slot0 | d.slot1;
-        return (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : 2;
-      };
-      for (int t = 0; t < np; ++t)
-        std::stable_sort(plan.patch_lanes.begin() + (size_t)t * block, plan.patch_lanes.begin() + (size_t)t * block + fill[t],
-                         [&](const LaneDesc &a, const LaneDesc &b) { return group(a) < group(b); });
+  if (order_groups) {
+    // (three groups: lanes that wait on another patch in a forward sweep -- a remote predecessor --, lanes that only do
+    //  so in a backward sweep, interior lanes: the first group alone polls global memory under Gauss-Seidel, the second
+    //  alone under backward SOR.  Each group starts on a wavefront of the 4-lane kernel (16 constraints) where the patch
+    //  has room for the idle lanes in between: a lane that only RELEASES to another patch then never shares a wavefront
+    //  with a polling one, so its own LDS hand-off is seen at once and not at the polling wavefront's next look.)
+    auto group = [](const LaneDesc &d) {
+      const int f = d.slot0 | d.slot1;
+      return (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : 2;
+    };
+    std::vector<LaneDesc> tmp;
+    for (int t = 0; t < np; ++t) {
+      LaneDesc *base = plan.patch_lanes.data() + (size_t)t * block;
+      std::stable_sort(base, base + fill[t], [&](const LaneDesc &a, const LaneDesc &b) { return group(a) < group(b); });
+      int n0 = 0, n1 = 0;
+      for (int k = 0; k < fill[t]; ++k) { n0 += group(base[k]) == 0; n1 += group(base[k]) == 1; }
+      const int unit = 16;
+      const int s1 = (n0 + unit - 1) / unit * unit, s2 = s1 + (n1 + unit - 1) / unit * unit;
+      const int total = s2 + (fill[t] - n0 - n1);
+      if (total > block || (n0 == 0 && n1 == 0)) continue;
+      tmp.assign(base, base + fill[t]);
+      std::fill(base, base + block, idle);
+      std::copy(tmp.begin(), tmp.begin() + n0, base);
+      std::copy(tmp.begin() + n0, tmp.begin() + n0 + n1, base + s1);
+      std::copy(tmp.begin() + n0 + n1, tmp.end(), base + s2);
+      fill[t] = total;
     }
   }
   if (overflow) {   // cannot happen with <= 512 sides per patch; keep the all-global path if it ever does
