@@ -34,7 +34,7 @@ EXPORTS = [
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
     "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig", "egs_box_lcp_murty",
-    "egs_box_lcp_batch", "egs_box_lcp_schur", "egs_dense_condition",
+    "egs_box_lcp_batch", "egs_box_lcp_schur", "egs_dense_condition", "egs_dense_iterate",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -194,6 +194,20 @@ class Context:
             self.check(st)
         return bool(ok.value), x, w, piv.value
 
+
+    def dense_iterate(self, A, b, prm, Ceq=None, lo=None, hi=None):
+        """sparse::{Jacobi,GaussSeidel,SOR}Iteration(A, b[, C, x_lo, x_hi]) on an explicit matrix: x, stats."""
+        A, b = _f64(A), _f64(b)
+        n = b.shape[0]
+        x = np.zeros(n)
+        st = SolveStats()
+        args = (None, None, None) if Ceq is None else (_p(_u8(Ceq)), _p(_f64(lo)), _p(_f64(hi)))
+        keep = (Ceq, lo, hi)
+        if Ceq is not None:
+            c8, l8, h8 = _u8(Ceq), _f64(lo), _f64(hi)
+            args = (_p(c8), _p(l8), _p(h8))
+        self.check(load().egs_dense_iterate(self.h, C.c_int32(n), _p(A), _p(b), args[0], args[1], args[2], C.byref(prm), _p(x), C.byref(st)))
+        return x, st
 
     def dense_condition(self, A):
         """GetConditionNumber of a symmetric positive definite matrix (utils.cc:256-261) on the device: (estimate, pivot bound)."""

@@ -1548,6 +1548,31 @@ egs_status egs_problem_dense_condition(egs_problem *p, double cfm, double *estim
   });
 }
 
+egs_status egs_dense_iterate(egs_context *ctx, int32_t N, const double *A, const double *b, const uint8_t *C, const double *lo,
+                             const double *hi, const egs_solve_params *params, double *x, egs_solve_stats *stats) {
+  if (!ctx) return EGS_ERR_INVALID;
+  if (egs_status st = validate_params(ctx, params)) return st;
+  if (N < 0 || (N > 0 && (!A || !b || !x))) return fail(ctx, EGS_ERR_INVALID, "NULL array");
+  if (N > 0 && (C || lo || hi) && !(C && lo && hi)) return fail(ctx, EGS_ERR_INVALID, "C, lo and hi come together (or all NULL: every row an equality)");
+  return guarded(ctx, [&]() -> egs_status {
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint8_t> all_eq;
+    std::vector<double> zeros;
+    if (!C) { all_eq.assign((size_t)std::max(N, 1), 1); zeros.assign((size_t)std::max(N, 1), 0.0); }   // sparse_iterations.cc:229-233
+    int it = 0;
+    double res = 0.0;
+    dense_iterate(ctx->stream, N, A, b, C ? C : all_eq.data(), lo ? lo : zeros.data(), hi ? hi : zeros.data(), params->method,
+                  params->omega, params->max_iters, params->tol, x, &it, &res);
+    if (stats) {
+      std::memset(stats, 0, sizeof *stats);
+      stats->iterations = it;
+      stats->residual = res;
+      stats->status = EGS_OK;
+    }
+    return EGS_OK;
+  });
+}
+
 egs_status egs_dense_condition(egs_context *ctx, int32_t N, const double *A, double *estimate, double *pivot_bound) {
   if (!ctx) return EGS_ERR_INVALID;
   if (N < 0 || !estimate || (N > 0 && !A)) return fail(ctx, EGS_ERR_INVALID, "NULL array");

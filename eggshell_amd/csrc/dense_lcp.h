@@ -66,4 +66,11 @@ bool box_lcp_schur(hipStream_t stream, int n, double *A, const double *b, const 
                    int nub_arg, bool q6, int max_steps, double max_seconds, double *x, double *w, int32_t *perm, int *nub_out,
                    int *pivots, std::string *msg);
 
+// sparse::{Jacobi,GaussSeidel,SOR}Iteration on an explicit dense matrix (sparse_iterations.cc:72-144; dense_iter.hip):
+// A row-major n x n (n <= 1024), C / lo / hi as the reference's 5-argument overloads (all-equality for the 2-argument
+// ones), method 0 / 1 / 2, omega = 1.5 in the reference (:15), max_iters = 500 (:19), tol = 1e-9 (constants.h:5).
+void dense_iterate(hipStream_t stream, int n, const double *A, const double *b, const uint8_t *C, const double *lo,
+                   const double *hi, int method, double omega, int max_iters, double tol, double *x, int *iterations,
+                   double *residual);
+
 }  // namespace egs

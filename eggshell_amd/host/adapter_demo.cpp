@@ -187,6 +187,16 @@ static void round2() {
       }
     VectorXd b(n), lo(n), hi(n), x, w;
     for (int i = 0; i < n; ++i) { b(i) = ((i * 5) % 7 - 3) * 1.5; lo(i) = -0.25; hi(i) = 0.5; }
+    {  // the iterations on an EXPLICIT matrix (sparse_iterations.h:13-24): 2-argument and 5-argument forms
+      MatrixXd Ad = A;
+      for (int i = 0; i < n; ++i) Ad(i, i) += 6.0;        // a little diagonal dominance, as the reference's tests add (:392)
+      print_vec("dense_gs_x", sparse::GaussSeidelIteration(Ad, b));
+      std::printf("dense_gs_iters %d\n", sparse::GetLastSolve().iterations);
+      print_vec("dense_sor_x", sparse::SORIteration(Ad, b));
+      ArrayXb Cm(n);
+      for (int i = 0; i < n; ++i) Cm(i) = (i % 3 == 0) ? 1 : 0;
+      print_vec("dense_gs_mixed_x", sparse::GaussSeidelIteration(Ad, b, Cm, lo, hi));
+    }
     const double inf = std::numeric_limits<double>::infinity();
     lo(3) = -inf; hi(3) = inf;
     lo(8) = -__DBL_MAX__; hi(8) = __DBL_MAX__;

@@ -206,6 +206,40 @@ VectorXd sparse::SORIteration(const ConstraintsList &c, const MatrixXd &M, const
 }
 sparse::LastSolve sparse::GetLastSolve() { return g_last; }
 
+// ---- the same three on an explicit matrix (sparse_iterations.cc:72-144, 229-267) ----------------
+namespace {
+VectorXd IterateDense(const MatrixXd &A, const VectorXd &b, const ArrayXb *C, const VectorXd *x_lo, const VectorXd *x_hi, int method) {
+  // CHECK(A.rows() == A.cols() && A.rows() == b.size()) (:77): the reference Panics
+  if (A.rows() != A.cols() || A.rows() != b.size()) throw egs::Error(EGS_ERR_INVALID, "BaseIteration: A must be square, b of its size");
+  if (C && (C->size() != b.size() || x_lo->size() != b.size() || x_hi->size() != b.size()))
+    throw egs::Error(EGS_ERR_INVALID, "BaseIteration: C, x_lo, x_hi of b's size");
+  const int n = b.size();
+  VectorXd x(n);
+  if (n == 0) return x;                            // :79-81
+  egs_solve_params prm;
+  egs_default_params(&prm);                       // omega 1.5, 500 sweeps, tol 1e-9: sparse_iterations.cc:15-19, constants.h:5
+  prm.method = method;
+  egs_solve_stats st;
+  egs_status rc = egs_dense_iterate(egs::DefaultContext(), n, A.data(), b.data(), C ? C->data() : nullptr, C ? x_lo->data() : nullptr,
+                                    C ? x_hi->data() : nullptr, &prm, x.data(), &st);
+  if (rc != EGS_OK) throw egs::Error(rc, egs_last_error(egs::DefaultContext()));
+  g_last = sparse::LastSolve{st.iterations, st.residual, 0, 0, 0};
+  return x;
+}
+}  // namespace
+VectorXd sparse::JacobiIteration(const MatrixXd &A, const VectorXd &b) { return IterateDense(A, b, nullptr, nullptr, nullptr, EGS_JACOBI); }
+VectorXd sparse::JacobiIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &lo, const VectorXd &hi) {
+  return IterateDense(A, b, &C, &lo, &hi, EGS_JACOBI);
+}
+VectorXd sparse::GaussSeidelIteration(const MatrixXd &A, const VectorXd &b) { return IterateDense(A, b, nullptr, nullptr, nullptr, EGS_GAUSS_SEIDEL); }
+VectorXd sparse::GaussSeidelIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &lo, const VectorXd &hi) {
+  return IterateDense(A, b, &C, &lo, &hi, EGS_GAUSS_SEIDEL);
+}
+VectorXd sparse::SORIteration(const MatrixXd &A, const VectorXd &b) { return IterateDense(A, b, nullptr, nullptr, nullptr, EGS_SOR); }
+VectorXd sparse::SORIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &lo, const VectorXd &hi) {
+  return IterateDense(A, b, &C, &lo, &hi, EGS_SOR);
+}
+
 // ---- sparse_iterations_utils.cc:427-695 ------------------------------------------
 namespace {
 VectorXd Product(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &x, int32_t parts,

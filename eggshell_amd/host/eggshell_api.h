@@ -141,7 +141,16 @@ typedef std::vector<std::shared_ptr<Joint>> JointsList;
 typedef std::vector<std::shared_ptr<Contact>> ContactsList;
 typedef std::vector<std::shared_ptr<Constraint>> ConstraintsList;
 
-namespace sparse {  // sparse_iterations.h:26-34
+namespace sparse {  // sparse_iterations.h:13-34
+// on an explicit matrix (sparse_iterations.h:13-24, sparse_iterations.cc:72-144): the 2-argument forms treat every
+// row as an equality, the 5-argument forms project the rows with C = false onto [x_lo, x_hi]
+VectorXd JacobiIteration(const MatrixXd &A, const VectorXd &b);
+VectorXd JacobiIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &x_lo, const VectorXd &x_hi);
+VectorXd GaussSeidelIteration(const MatrixXd &A, const VectorXd &b);
+VectorXd GaussSeidelIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &x_lo, const VectorXd &x_hi);
+VectorXd SORIteration(const MatrixXd &A, const VectorXd &b);
+VectorXd SORIteration(const MatrixXd &A, const VectorXd &b, const ArrayXb &C, const VectorXd &x_lo, const VectorXd &x_hi);
+// matrix-free, on an ensemble's constraints (sparse_iterations.h:26-34)
 VectorXd JacobiIteration(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &rhs,
                          double cfm = 0.0);
 VectorXd GaussSeidelIteration(const ConstraintsList &constraints, const MatrixXd &M_inverse, const VectorXd &rhs,

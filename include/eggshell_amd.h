@@ -262,6 +262,20 @@ egs_status egs_mixed_constraints_solve_limits(egs_context *ctx, int32_t N, const
                                               int32_t use_bounds, int32_t max_pivots, double max_seconds,
                                               double *x, double *w, int32_t *ok, int32_t *pivots);
 
+/* Replaces sparse::JacobiIteration / GaussSeidelIteration / SORIteration on an EXPLICIT matrix:
+ *   VectorXd sparse::XIteration(const MatrixXd& A, const VectorXd& b)                                    sparse_iterations.h:13-24
+ *   VectorXd sparse::XIteration(const MatrixXd& A, const VectorXd& b, const ArrayXb& C, x_lo, x_hi)
+ * i.e. BaseIteration(A, b, ...) of sparse_iterations.cc:72-144 with its dense solves
+ * (sparse_iterations_utils.cc:25-40, 110-128, 245-262) and stopping test (:35-49, 128-141): x0 = b,
+ * one sweep, one residual, stop at err <= tol or after max_iters sweeps.  A [N][N] row-major (general,
+ * need not be symmetric; non-zero diagonal), N <= 1024; C / lo / hi all NULL = the 2-argument form
+ * (every row an equality).  params: method, omega, max_iters, tol as for entry 1 (cfm unused: it is in A).
+ * stats: iterations, residual.  The reference's spectral-radius gate (:113-121, Panic when
+ * rho(M^-1 N) >= 1) is not evaluated: a diverging splitting runs to max_iters and reports its residual. */
+egs_status egs_dense_iterate(egs_context *ctx, int32_t N, const double *A, const double *b, const uint8_t *C,
+                             const double *lo, const double *hi, const egs_solve_params *params, double *x,
+                             egs_solve_stats *stats);
+
 /* ---- the dense front half of Ensemble::ComputeVDot (ensembles.cc:498-538) on
  *      the device, for the sizes the reference's dense solver is meant for
  *      (Chain, Cairn): the problem's blocks (assemble or set_blocks) -> dense

@@ -163,6 +163,13 @@ int orc_mixed_constraints(int dim, const double *A, const double *b,
 
 /* ---- collision (collision.cc), used to build the synthetic contact sets -- */
 /* collision.cc:408-436. contacts: [<=8][7] = pos(3), normal(3), depth. */
+/* ---- the iterations on an explicit dense matrix (dense_iter.c): sparse_iterations.cc:35-49, 72-144 and the dense
+ *      twins of sparse_iterations_utils.cc:25-40, 110-128, 245-262.  A row-major n x n. */
+double orc_dense_residual(int n, const double *A, const double *b, const double *x, const uint8_t *C, const double *lo,
+                          const double *hi);
+int orc_dense_iterate(int n, const double *A, const double *b, const uint8_t *C, const double *lo, const double *hi,
+                      int method, double omega, int max_iters, double tol, double *x, double *residual_out);
+
 /* ---- toolkit/lcp.cc: incremental-factor box LCP (lcp_toolkit.c).  Row-major n x n, lower triangle only. */
 int otk_cholesky(double *L, int n);
 void otk_lsolve(const double *L, int n, int m, double *x);

@@ -318,6 +318,21 @@ def mixed_constraints(A, b, Ceq, lo, hi, use_bounds=0):
     return bool(ok), x, w, piv.value
 
 
+# ---- iterations on an explicit dense matrix (dense_iter.c) --------------------
+def dense_iterate(A, b, method, Ceq=None, lo=None, hi=None, omega=1.5, max_iters=500, tol=1e-9):
+    """sparse::{Jacobi,GaussSeidel,SOR}Iteration(A, b[, C, x_lo, x_hi]) (sparse_iterations.cc:72-144): x, sweeps, residual."""
+    A, b = _f64(A), _f64(b)
+    n = b.shape[0]
+    Ceq = np.ones(n, np.uint8) if Ceq is None else np.ascontiguousarray(Ceq, dtype=np.uint8)
+    lo = np.zeros(n) if lo is None else _f64(lo)
+    hi = np.zeros(n) if hi is None else _f64(hi)
+    x = np.zeros(n); res = C.c_double(0)
+    fn = lib().orc_dense_iterate
+    it = fn(C.c_int(n), _p(A), _p(b), _p(Ceq), _p(lo), _p(hi), C.c_int(method), C.c_double(omega), C.c_int(max_iters),
+            C.c_double(tol), _p(x), C.byref(res))
+    return x, int(it), res.value
+
+
 # ---- toolkit/lcp.cc: incremental-factor box LCP (lcp_toolkit.c) --------------
 def tk_cholesky(A):
     L = _f64(A).copy()

@@ -172,6 +172,15 @@ def test_solvelcp_contract(out):
         assert np.abs(w[inside]).max(initial=0) < 1e-9
         assert (w[box & (x == lo)] >= -1e-9).all() and (w[box & (x == hi)] <= 1e-9).all()
 
+    # sparse::{GaussSeidel,SOR}Iteration on an explicit matrix through the reference's signatures
+    Ad = A + 6.0 * np.eye(n)
+    lo0, hi0 = np.full(n, -0.25), np.full(n, 0.5)
+    xg, itg, _ = orc.dense_iterate(Ad, b, orc.GAUSS_SEIDEL)
+    assert np.abs(out["dense_gs_x"] - xg).max() < 1e-12 and abs(int(out["dense_gs_iters"][0]) - itg) <= 1
+    assert np.linalg.norm(Ad @ out["dense_gs_x"] - b) < 1e-9 and np.linalg.norm(Ad @ out["dense_sor_x"] - b) < 1e-9
+    Cm = (np.arange(n) % 3 == 0)
+    xm, _, _ = orc.dense_iterate(Ad, b, orc.GAUSS_SEIDEL, Cm, lo0, hi0)
+    assert np.abs(out["dense_gs_mixed_x"] - xm).max() < 1e-12
     # default settings: rows 3 and 8 are unbounded (eliminated first), row 5 keeps its finite hi
     assert int(out["lcp_default_ok"][0]) == 1
     unb = np.zeros(n, bool); unb[[3, 8]] = True
