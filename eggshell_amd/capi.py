@@ -34,7 +34,7 @@ EXPORTS = [
     "egs_world_get_lambda", "egs_world_info",
     "egs_problem_matvec", "egs_problem_get_matvec", "egs_problem_get_wres", "egs_matvec_blocks",
     "egs_debug_matvec_plan", "egs_debug_choose_oversize_schedule", "egs_debug_plan_timetable", "egs_box_lcp_dantzig", "egs_box_lcp_murty",
-    "egs_box_lcp_batch", "egs_box_lcp_schur", "egs_dense_condition", "egs_dense_iterate",
+    "egs_box_lcp_batch", "egs_box_lcp_schur", "egs_dense_condition", "egs_dense_iterate", "egs_debug_plan_patches", "egs_problem_debug_trace",
     "egs_mixed_constraints_solve_limits", "egs_problem_dense_system", "egs_problem_dense_condition", "egs_problem_step_dense",
 ]
 
@@ -86,6 +86,18 @@ def _i32(a):
 
 def _u8(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def debug_plan_patches(n_bodies, body0, body1):
+    """Host only: the body patches of an oversize island -- n_patches, patch / lane per constraint, remote flags per side."""
+    b0, b1 = _i32(body0), _i32(body1)
+    m = b0.shape[0]
+    npat = C.c_int32(0)
+    cp, cl, r0, r1 = (np.zeros(m, np.int32) for _ in range(4))
+    st = load().egs_debug_plan_patches(C.c_int32(n_bodies), C.c_int32(m), _p(b0), _p(b1), C.byref(npat), _p(cp), _p(cl), _p(r0), _p(r1))
+    if st != OK:
+        raise RuntimeError("egs_debug_plan_patches failed: %d" % st)
+    return npat.value, cp, cl, r0, r1
 
 
 def params(method=GAUSS_SEIDEL, max_iters=500, tol=1e-9, cfm=0.0, omega=1.5, check_every=1):
@@ -354,6 +366,13 @@ class Problem:
         x = np.zeros(3 * self.m)
         self.ctx.check(load().egs_problem_get_lambda(self.h, _p(x)))
         return x
+
+    def debug_trace(self, max_sweeps=1000):
+        """EGS_TRACE_UPDATES=1: completion stamps [sweeps][m] (100 MHz ticks) of the last 4-lane patch launch."""
+        buf = np.zeros(max_sweeps * self.m, np.uint64)
+        sw = C.c_int32(0)
+        self.ctx.check(load().egs_problem_debug_trace(self.h, _p(buf), C.c_int64(buf.shape[0]), C.byref(sw)))
+        return buf[:sw.value * self.m].reshape(sw.value, self.m)
 
     def wres(self):
         """w = A lambda - rhs of the last solve (the solve kernels' epilogue)."""

@@ -226,6 +226,8 @@ struct egs_problem {
   DevBuf<unsigned char> wsB0, wsB1, wsD, wsInv;
   DevBuf<GlobalDesc> gcons;
   DevBuf<uint32_t> gtickets;
+  DevBuf<unsigned long long> trace;   // EGS_TRACE_UPDATES=1: [sweeps][m] completion times of the last patch launch
+  int trace_sweeps = 0;
   DevBuf<unsigned char> ggran;   // [n][6] x 16 B: data-tagged granules of the 4-lane body patches (quad_solve.hip)
   uint32_t gran_epoch = 0;
   // oversize islands as body patches (GS/SOR): LDS for private bodies, global for shared
@@ -501,6 +503,12 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
           a.gran = p->ggran.p;
           a.gran_epoch = p->gran_epoch;
         }
+      }
+      if (std::getenv("EGS_TRACE_UPDATES") && sweeps > 0) {
+        p->trace.alloc((size_t)sweeps * p->m);
+        HIPCHK(hipMemsetAsync(p->trace.p, 0, (size_t)sweeps * p->m * sizeof(unsigned long long), ctx->stream));
+        p->trace_sweeps = sweeps;
+        a.trace = p->trace.p;
       }
       // 4 lanes per constraint, 1024-thread patches: the LDS hop is about half as long
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
@@ -968,6 +976,7 @@ egs_status egs_context_create(int device_index, egs_context **out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_index));
     if (prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    set_patch_workgroups(ctx->cu_count);
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ctx->t0));
     HIPCHK(hipEventCreate(&ctx->t1));
@@ -1787,6 +1796,45 @@ egs_status egs_debug_plan(int32_t n, int32_t m, const int32_t *body0, const int3
       if (pos1) pos1[g.cidx] = g.pos1;
       if (cnt1) cnt1[g.cidx] = g.cnt1;
     }
+    return EGS_OK;
+  } catch (const std::exception &) {
+    return EGS_ERR_INVALID;
+  }
+}
+
+egs_status egs_problem_debug_trace(egs_problem *p, uint64_t *out, int64_t count, int32_t *sweeps) {
+  if (!p || !out) return EGS_ERR_INVALID;
+  return guarded(p->ctx, [&]() -> egs_status {
+    if (sweeps) *sweeps = p->trace_sweeps;
+    const int64_t have = (int64_t)p->trace_sweeps * p->m;
+    if (have <= 0 || count < have) return fail(p->ctx, EGS_ERR_INVALID, "no trace recorded (EGS_TRACE_UPDATES=1, an island on 4-lane patches) or buffer too small");
+    HIPCHK(hipMemcpyAsync(out, p->trace.p, (size_t)have * sizeof(uint64_t), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return EGS_OK;
+  });
+}
+
+egs_status egs_debug_plan_patches(int32_t n, int32_t m, const int32_t *body0, const int32_t *body1, int32_t *n_patches,
+                                  int32_t *cons_patch, int32_t *cons_lane, int32_t *remote0, int32_t *remote1) {
+  if (n < 0 || m < 0 || (m > 0 && (!body0 || !body1))) return EGS_ERR_INVALID;
+  try {
+    const Plan pl = build_plan(n, m, body0, body1, 256);
+    if (n_patches) *n_patches = pl.n_patch_tiles;
+    for (int i = 0; i < m; ++i) {
+      if (cons_patch) cons_patch[i] = -1;
+      if (cons_lane) cons_lane[i] = -1;
+      if (remote0) remote0[i] = 0;
+      if (remote1) remote1[i] = 0;
+    }
+    for (int t = 0; t < pl.n_patch_tiles; ++t)
+      for (int l = 0; l < pl.block; ++l) {
+        const LaneDesc &d = pl.patch_lanes[(size_t)t * pl.block + l];
+        if (d.cidx < 0) continue;
+        if (cons_patch) cons_patch[d.cidx] = t;
+        if (cons_lane) cons_lane[d.cidx] = l;
+        if (remote0) remote0[d.cidx] = ((d.slot0 & kPrevRemote) ? 1 : 0) | ((d.slot0 & kNextRemote) ? 2 : 0);
+        if (remote1) remote1[d.cidx] = ((d.slot1 & kPrevRemote) ? 1 : 0) | ((d.slot1 & kNextRemote) ? 2 : 0);
+      }
     return EGS_OK;
   } catch (const std::exception &) {
     return EGS_ERR_INVALID;

@@ -50,6 +50,8 @@ struct SolveArgs {
   // 16-byte granules {value, launch epoch << 32 | ticket} (quad_solve.hip); NULL = the flag protocol (g_tick)
   void *gran = nullptr;        // [n_bodies][6] x 16 B
   uint32_t gran_epoch = 0;
+  // diagnostics (EGS_TRACE_UPDATES=1): completion time (100 MHz wall clock) of every update of the 4-lane patch kernel
+  unsigned long long *trace = nullptr;   // [sweeps][m]
 };
 
 template <typename REAL>

@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
+#include <string>
+#include <utility>
 
 namespace egs {
 
@@ -31,6 +33,8 @@ namespace {
 // Cut the oversize islands into patches (see plan.h).  On any obstacle (a body
 // owning more constraints than a tile holds, 16-bit overflow) the patch plan is
 // left empty and the caller uses the all-global path.
+int g_patch_workgroups = 256;     // CUs of the device the plans are built for (set_patch_workgroups)
+
 void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t *body1,
                    const std::vector<int32_t> &cnt, const std::vector<int32_t> &pos0,
                    const std::vector<int32_t> &pos1) {
@@ -38,7 +42,21 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
   const int mg = (int)plan.global.size();
   // head-room for the idle lanes that align the lane groups to wavefronts (below)
   const bool order_groups = [] { const char *e = std::getenv("EGS_PATCH_ORDER"); return !(e && std::atoi(e) == 0); }();
-  const int cap = (order_groups && block >= 128) ? block - 32 : block;
+  // How many constraints per patch.  Measured on MI355X (tools/trace_patches.py): on the critical chain of a wall a
+  // hand-off ACROSS patches costs 1.4 us, but one INSIDE a full 224-constraint patch 0.8 us instead of the 0.2-0.4 us of
+  // an unloaded chain -- the patch's sixteen wavefronts share four SIMDs and every look of a waiting wavefront is ~100
+  // VALU instructions for one or two ready constraints.  So the island is spread over as many CUs as there are
+  // (g_patch_workgroups, all patches must be co-resident: one workgroup per CU), down to 48 constraints per patch.
+  int cap = (order_groups && block >= 128) ? block - 32 : block;
+  {
+    const char *e = std::getenv("EGS_PATCH_CAP");
+    const int forced = e ? std::atoi(e) : 0;
+    if (forced >= 16 && forced <= block) cap = forced;
+    else if (block >= 128) {
+      const int target = (int)((mg + (long)(g_patch_workgroups * 9 / 10) - 1) / std::max(1, g_patch_workgroups * 9 / 10));
+      cap = std::min(cap, std::max(48, (target + 15) / 16 * 16));
+    }
+  }
   // owner body of a constraint = its first real body
   auto owner = [&](int c) { return body0[c] >= 0 ? body0[c] : body1[c]; };
   std::vector<int32_t> owned(n_bodies, 0);
@@ -52,28 +70,82 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
       if (b >= 0) { touch[b].push_back(g); in_big[b] = 1; if (cnt[b] > 65535) return; }
   }
   for (int b = 0; b < n_bodies; ++b) if (owned[b] > block) return;
-  // BFS-grown patches, seeds in ascending body index
-  std::vector<int32_t> patch_of(n_bodies, -1);
-  std::vector<int32_t> patch_fill;
-  std::vector<int32_t> queue;
-  for (int seed = 0; seed < n_bodies; ++seed) {
-    if (!in_big[seed] || patch_of[seed] >= 0) continue;
-    const int pid = (int)patch_fill.size();
-    patch_fill.push_back(0);
-    queue.clear();
-    queue.push_back(seed);
-    for (size_t qh = 0; qh < queue.size(); ++qh) {
-      const int b = queue[qh];
-      if (patch_of[b] >= 0) continue;
-      if (patch_fill[pid] + owned[b] > (owned[b] > cap ? block : cap)) continue;   // does not fit: left for a later patch
-      patch_of[b] = pid;
-      patch_fill[pid] += owned[b];
-      for (int g : touch[b]) {
-        const int c = plan.global[g].cidx;
-        for (int nb : {body0[c], body1[c]})
-          if (nb >= 0 && patch_of[nb] < 0) queue.push_back(nb);
+  // Two ways to cut the island's bodies into patches; the one whose WORST body crosses patches least often per sweep
+  // is taken (then the fewer crossings in total).  A body's constraint list is walked cyclically every sweep and every
+  // change of patch along it is a hand-off through global memory (~4 us against 0.2-0.4 us in LDS), so the busiest
+  // body's count of changes sets the sweep period of the whole island:
+  //   blobs  -- BFS-grown from seeds in ascending body index: compact, most bodies never leave their patch, but a body
+  //             where three or four blobs meet changes patch up to four times per sweep;
+  //   chunks -- runs of consecutive body indices: the collider numbers bodies layer by layer, so a body's earlier
+  //             neighbours (the owners of the constraints it does not own) sit in the chunk(s) just before its own and
+  //             the list changes patch twice, three times where a chunk border cuts between them.
+  // (EGS_PATCH_SHAPE=blobs / chunks forces one.)
+  auto grow_blobs = [&](std::vector<int32_t> &patch_of, std::vector<int32_t> &patch_fill) {
+    patch_of.assign(n_bodies, -1);
+    patch_fill.clear();
+    std::vector<int32_t> queue;
+    for (int seed = 0; seed < n_bodies; ++seed) {
+      if (!in_big[seed] || patch_of[seed] >= 0) continue;
+      const int pid = (int)patch_fill.size();
+      patch_fill.push_back(0);
+      queue.clear();
+      queue.push_back(seed);
+      for (size_t qh = 0; qh < queue.size(); ++qh) {
+        const int b = queue[qh];
+        if (patch_of[b] >= 0) continue;
+        if (patch_fill[pid] + owned[b] > (owned[b] > cap ? block : cap)) continue;   // does not fit: left for a later patch
+        patch_of[b] = pid;
+        patch_fill[pid] += owned[b];
+        for (int g : touch[b]) {
+          const int c = plan.global[g].cidx;
+          for (int nb : {body0[c], body1[c]})
+            if (nb >= 0 && patch_of[nb] < 0) queue.push_back(nb);
+        }
+        if (patch_fill[pid] >= cap) break;
       }
-      if (patch_fill[pid] >= cap) break;
+    }
+  };
+  auto cut_chunks = [&](std::vector<int32_t> &patch_of, std::vector<int32_t> &patch_fill) {
+    patch_of.assign(n_bodies, -1);
+    patch_fill.assign(1, 0);
+    for (int b = 0; b < n_bodies; ++b) {
+      if (!in_big[b]) continue;
+      if (patch_fill.back() > 0 && patch_fill.back() + owned[b] > (owned[b] > cap ? block : cap)) patch_fill.push_back(0);
+      patch_of[b] = (int)patch_fill.size() - 1;
+      patch_fill.back() += owned[b];
+    }
+  };
+  // (worst body's patch changes per sweep, all bodies' changes) of an assignment
+  auto crossings = [&](const std::vector<int32_t> &patch_of) {
+    int worst = 0;
+    long total = 0;
+    for (int b = 0; b < n_bodies; ++b) {
+      const int k_n = (int)touch[b].size();
+      if (k_n < 2) continue;
+      int ch = 0;
+      int prev = patch_of[owner(plan.global[touch[b][k_n - 1]].cidx)];
+      for (int k = 0; k < k_n; ++k) {
+        const int t = patch_of[owner(plan.global[touch[b][k]].cidx)];
+        ch += t != prev;
+        prev = t;
+      }
+      worst = std::max(worst, ch);
+      total += ch;
+    }
+    return std::make_pair(worst, total);
+  };
+  std::vector<int32_t> patch_of, patch_fill;
+  {
+    const char *e = std::getenv("EGS_PATCH_SHAPE");
+    const std::string shape = e ? e : "";
+    if (shape == "chunks") cut_chunks(patch_of, patch_fill);
+    else {
+      grow_blobs(patch_of, patch_fill);
+      if (shape != "blobs") {
+        std::vector<int32_t> po2, pf2;
+        cut_chunks(po2, pf2);
+        if (crossings(po2) < crossings(patch_of)) { patch_of.swap(po2); patch_fill.swap(pf2); }
+      }
     }
   }
   // drop empty patches (bodies that own nothing) by renumbering patches with constraints
@@ -155,9 +227,14 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     //  alone under backward SOR.  Each group starts on a wavefront of the 4-lane kernel (16 constraints) where the patch
     //  has room for the idle lanes in between: a lane that only RELEASES to another patch then never shares a wavefront
     //  with a polling one, so its own LDS hand-off is seen at once and not at the polling wavefront's next look.)
-    auto group = [](const LaneDesc &d) {
+    // (the first and the last constraint of a SHARED body's list also run the cross-patch code -- the launch-boundary
+    //  cases of the kernels -- although they never poll: they go with the second group)
+    auto shared_end = [&](int b, unsigned pos, unsigned cn) { return b >= 0 && shared[b] && (pos == 0u || pos + 1u == cn); };
+    auto group = [&](const LaneDesc &d) {
       const int f = d.slot0 | d.slot1;
-      return (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : 2;
+      if (f & kPrevRemote) return 0;
+      if (f & kNextRemote) return 1;
+      return (shared_end(body0[d.cidx], d.pos0, d.cnt0) || shared_end(body1[d.cidx], d.pos1, d.cnt1)) ? 1 : 2;
     };
     std::vector<LaneDesc> tmp;
     for (int t = 0; t < np; ++t) {
@@ -599,5 +676,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   if (!plan.global.empty()) build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1);
   return plan;
 }
+
+void set_patch_workgroups(int n) { if (n > 0) g_patch_workgroups = n; }
 
 }  // namespace egs

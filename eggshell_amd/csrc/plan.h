@@ -89,4 +89,7 @@ constexpr int kAutoQuadBlock = 0;
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
                 int block, Plan *recycle = nullptr, int max_run_tiles = 0);
 
+// how many workgroups (CUs) an oversize island's patches may occupy at once: sizes the patches (plan.cpp::build_patches)
+void set_patch_workgroups(int n);
+
 }  // namespace egs

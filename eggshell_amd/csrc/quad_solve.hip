@@ -17,6 +17,8 @@
 // 1024-thread workgroup when islands are larger than 64 constraints.
 #include <stdexcept>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "solve_device.h"
 
@@ -291,24 +293,34 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     bool alive = active && A.sweeps >= 1;
     const unsigned tick_addr = lds_addr(my_tick), acc_addr = lds_addr(my_acc);
     // sweep order: forward = list order, backward = reversed, so the neighbours swap roles
-    const bool acq_side = (METHOD == 1) ? prev_remote : next_remote, rel_side = (METHOD == 1) ? next_remote : prev_remote;
+    // A wavefront none of whose lanes touches a body that other patches share runs the loop WITHOUT the cross-patch
+    // code: the general loop's sixteen exec-masked branches (acquire / release / launch-boundary cases) and the
+    // vmcnt(0) the compiler puts at their merge point cost ~0.35 us per look even when no lane takes them
+    // (tools/trace_patches.py: 0.7 us per LDS-local hand-off on the critical chain against 0.36 in the tile kernel).
+    // The plan puts a patch's boundary constraints first (plan.cpp), so the interior ones fill such wavefronts.
+    // (a lane needs that code if a list-order neighbour on its body is remote, or if it is the first / last constraint of a
+    //  shared body's list: the launch-boundary cases)
+    const bool wave_remote = PATCH && __any((has && (prev_remote || next_remote || (sh && (pos == 0u || pos == cnt - 1u)))) ? 1 : 0);
+    auto sweeps_loop = [&](auto remote_tag) {
+    constexpr bool REMOTE = decltype(remote_tag)::value;
+    const bool acq_side = REMOTE && ((METHOD == 1) ? prev_remote : next_remote), rel_side = REMOTE && ((METHOD == 1) ? next_remote : prev_remote);
     while (alive) {
       unsigned t;
       REAL a[3];
       // a shared body's first update of a resumed launch reads global memory, its last update of
       // the launch writes it (the accumulator must not stay behind in some patch's LDS)
-      const bool first_of_launch = sh && A.resume && sweep == 1 && ord == 0u;
-      const bool last_of_launch = sh && sweep == A.sweeps && ord == cnt - 1u;
+      const bool first_of_launch = REMOTE && sh && A.resume && sweep == 1 && ord == 0u;
+      const bool last_of_launch = REMOTE && sh && sweep == A.sweeps && ord == cnt - 1u;
       const bool acq = acq_side || first_of_launch;
       const bool rel = rel_side || last_of_launch;
       // granules: a predecessor in another patch of THIS launch is polled for; at the launch boundary the value is in A.acc
-      const bool acq_g = gran && acq_side && !first_of_launch;
+      const bool acq_g = REMOTE && gran && acq_side && !first_of_launch;
       REAL ga[3] = {REAL(0), REAL(0), REAL(0)};
       unsigned gt = want;
       if (acq_g) gt = gran_poll3<REAL>(my_gran, epoch_hi | want, ga) ? want : want + 1u;
-      else if (acq && !gran) gt = gld(g_t);
+      else if (REMOTE && acq && !gran) gt = gld(g_t);
       poll3(tick_addr, acc_addr, t, a);
-      if (acq) t = gt;
+      if (REMOTE && acq) t = gt;
       int rdy = (!has || t == want) ? 1 : 0;
       rdy &= dpp_i<kXor1>(rdy);
       rdy &= dpp_i<kXor2>(rdy);
@@ -316,7 +328,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         if (acq_g) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = ga[k];
-        } else if (acq) {
+        } else if (REMOTE && acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
@@ -363,14 +375,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             an[k] = tfma(Bh[3 * k + 2], dx[2], u);
             an_hist[k] = an[k];
           }
-          if (gran && rel) {
+          if (REMOTE && gran && rel) {
             if (last_of_launch) {
 #pragma unroll
               for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             } else {
               gran_store3<REAL>(my_gran, an, epoch_hi | (want + 1u));
             }
-          } else if (rel) {
+          } else if (REMOTE && rel) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -381,6 +393,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
             if (half == 0) store_tick(tick_addr, want + 1u);
           }
         }
+        if (PATCH && A.trace != nullptr && q == 0) A.trace[(size_t)(sweep - 1) * A.m + d.cidx] = wall_clock64();
         if (HIST) {   // snapshots for the per-sweep stopping test (kernels.h)
           if (q == 0) {
             REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
@@ -405,8 +418,10 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       }
       // a wavefront with a lane that waits on a global ticket has to keep looking (nothing wakes
       // it); one whose lanes all wait on LDS tickets sleeps until a ticket store of its workgroup
-      if (!__any(rdy) && !(PATCH && __any(alive && acq))) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
+      if (!__any(rdy) && !(REMOTE && __any(alive && acq))) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
     }
+    };
+    if (wave_remote) sweeps_loop(std::true_type{}); else sweeps_loop(std::false_type{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }

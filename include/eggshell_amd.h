@@ -419,6 +419,16 @@ egs_status egs_box_lcp_schur(egs_context *ctx, int32_t n, double *A, const doubl
  * per-body tickets (rank/count of the constraint among its body's, list
  * order) that make the parallel sweep reproduce the reference's list order
  * (sparse_iterations_utils.cc:159-243, 292-373).  Arrays [m], may be NULL.   */
+/* Diagnostics: with EGS_TRACE_UPDATES=1 in the environment the 4-lane patch kernel stamps every update with the
+ * device's 100 MHz wall clock; this copies the stamps of the problem's last such launch, [sweeps][m] (0 = not
+ * written), for tools/trace_patches.py, which walks the critical chain of the sweep pipeline.                  */
+egs_status egs_problem_debug_trace(egs_problem *p, uint64_t *out, int64_t count, int32_t *sweeps);
+/* The body patches an oversize island is cut into (plan.cpp::build_patches): per constraint its patch (-1: none),
+ * its lane in the patch, and per side bit 0 = the list-order predecessor on that body sits in another patch, bit 1 =
+ * the successor does (the hand-offs that cross global memory).  Arrays [m], may be NULL.                      */
+egs_status egs_debug_plan_patches(int32_t n_bodies, int32_t m, const int32_t *body0, const int32_t *body1,
+                                  int32_t *n_patches, int32_t *cons_patch, int32_t *cons_lane, int32_t *remote0,
+                                  int32_t *remote1);
 egs_status egs_debug_plan(int32_t n_bodies, int32_t m, const int32_t *body0,
                           const int32_t *body1, int32_t tile_size,
                           int32_t *n_islands, int32_t *n_tiles,
