@@ -418,7 +418,11 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       }
       // a wavefront with a lane that waits on a global ticket has to keep looking (nothing wakes
       // it); one whose lanes all wait on LDS tickets sleeps until a ticket store of its workgroup
-      if (!__any(rdy) && !(REMOTE && __any(alive && acq))) __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
+      // (in a patch few wavefronts are awake at a time and the next constraint in line often sits in another one: a
+      //  short nap -- 128 cycles instead of 2048 -- finds its ticket sooner: walls another 4 %)
+      if (!__any(rdy) && !(REMOTE && __any(alive && acq))) {
+        if (PATCH) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
+      }
     }
     };
     if (wave_remote) sweeps_loop(std::true_type{}); else sweeps_loop(std::false_type{});
