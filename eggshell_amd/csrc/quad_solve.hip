@@ -300,27 +300,33 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     // The plan puts a patch's boundary constraints first (plan.cpp), so the interior ones fill such wavefronts.
     // (a lane needs that code if a list-order neighbour on its body is remote, or if it is the first / last constraint of a
     //  shared body's list: the launch-boundary cases)
-    const bool wave_remote = PATCH && __any((has && (prev_remote || next_remote || (sh && (pos == 0u || pos == cnt - 1u)))) ? 1 : 0);
-    auto sweeps_loop = [&](auto remote_tag) {
-    constexpr bool REMOTE = decltype(remote_tag)::value;
-    const bool acq_side = REMOTE && ((METHOD == 1) ? prev_remote : next_remote), rel_side = REMOTE && ((METHOD == 1) ? next_remote : prev_remote);
+    const bool acq_flag = (METHOD == 1) ? prev_remote : next_remote;
+    const bool lane_remote = has && (prev_remote || next_remote || (sh && (pos == 0u || pos == cnt - 1u)));
+    const bool lane_acquires = has && (acq_flag || (sh && A.resume && ord == 0u));
+    // three loops: 0 = no cross-patch code at all, 1 = releases only (stores; no global load, hence no vmcnt wait that
+    // would hold the wavefront until its own write-through stores are acknowledged), 2 = everything
+    const int wave_level = !PATCH ? 0 : (__any(lane_acquires ? 1 : 0) ? 2 : (__any(lane_remote ? 1 : 0) ? 1 : 0));
+    auto sweeps_loop = [&](auto level_tag) {
+    constexpr int LEVEL = decltype(level_tag)::value;
+    constexpr bool REMOTE = LEVEL >= 1, ACQ = LEVEL == 2;
+    const bool acq_side = ACQ && acq_flag, rel_side = REMOTE && ((METHOD == 1) ? next_remote : prev_remote);
     while (alive) {
       unsigned t;
       REAL a[3];
       // a shared body's first update of a resumed launch reads global memory, its last update of
       // the launch writes it (the accumulator must not stay behind in some patch's LDS)
-      const bool first_of_launch = REMOTE && sh && A.resume && sweep == 1 && ord == 0u;
+      const bool first_of_launch = ACQ && sh && A.resume && sweep == 1 && ord == 0u;
       const bool last_of_launch = REMOTE && sh && sweep == A.sweeps && ord == cnt - 1u;
       const bool acq = acq_side || first_of_launch;
       const bool rel = rel_side || last_of_launch;
       // granules: a predecessor in another patch of THIS launch is polled for; at the launch boundary the value is in A.acc
-      const bool acq_g = REMOTE && gran && acq_side && !first_of_launch;
+      const bool acq_g = ACQ && gran && acq_side && !first_of_launch;
       REAL ga[3] = {REAL(0), REAL(0), REAL(0)};
       unsigned gt = want;
       if (acq_g) gt = gran_poll3<REAL>(my_gran, epoch_hi | want, ga) ? want : want + 1u;
-      else if (REMOTE && acq && !gran) gt = gld(g_t);
+      else if (ACQ && acq && !gran) gt = gld(g_t);
       poll3(tick_addr, acc_addr, t, a);
-      if (REMOTE && acq) t = gt;
+      if (ACQ && acq) t = gt;
       int rdy = (!has || t == want) ? 1 : 0;
       rdy &= dpp_i<kXor1>(rdy);
       rdy &= dpp_i<kXor2>(rdy);
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
         if (acq_g) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = ga[k];
-        } else if (REMOTE && acq) {
+        } else if (ACQ && acq) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
@@ -420,12 +426,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       // it); one whose lanes all wait on LDS tickets sleeps until a ticket store of its workgroup
       // (in a patch few wavefronts are awake at a time and the next constraint in line often sits in another one: a
       //  short nap -- 128 cycles instead of 2048 -- finds its ticket sooner: walls another 4 %)
-      if (!__any(rdy) && !(REMOTE && __any(alive && acq))) {
+      if (!__any(rdy) && !(ACQ && __any(alive && acq))) {
         if (PATCH) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(EGS_QUAD_SLEEP);
       }
     }
     };
-    if (wave_remote) sweeps_loop(std::true_type{}); else sweeps_loop(std::false_type{});
+    if (wave_level == 2) sweeps_loop(std::integral_constant<int, 2>{});
+    else if (wave_level == 1) sweeps_loop(std::integral_constant<int, 1>{});
+    else sweeps_loop(std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }

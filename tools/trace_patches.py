@@ -69,7 +69,8 @@ while True:
         break
     lat = T[s, c] - best[0]
     same_patch = cp[c] == cp[best[2]]
-    key = ("same patch, same wavefront" if same_patch and wave[c] == wave[best[2]] else "same patch, other wavefront") if same_patch else "ACROSS patches"
+    grp = "poller" if ((r0[c] | r1[c]) & 1) else ("releaser" if ((r0[c] | r1[c]) & 2) else "interior")
+    key = (("same patch, same wavefront" if same_patch and wave[c] == wave[best[2]] else "same patch, other wavefront") if same_patch else "ACROSS patches") + " -> " + grp
     e = classes.setdefault(key, {"edges": 0, "us": 0.0})
     e["edges"] += 1; e["us"] += float(lat)
     chain.append((int(s), int(c), float(lat), key))
