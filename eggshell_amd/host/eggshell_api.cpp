@@ -651,8 +651,16 @@ bool Ensemble::StepOnDevice(double dt) {
 }
 
 void Ensemble::Step(double dt, Integrator g) {  // ensembles.cc:390-427
+  // The reference cannot complete a step with either of the other two: IMPLICIT_MIDPOINT Panics outright
+  // (ensembles.cc:403-405) and EXPLICIT_EULER reaches ComputeJDotV_Joints(), whose first statement is a Panic
+  // (ensembles.cc:94-97). There is no behaviour to reproduce, so both are refused with the reference's reason.
+  if (g == Integrator::IMPLICIT_MIDPOINT)
+    throw egs::Error(EGS_ERR_UNSUPPORTED,
+                     "Implicit midpoint integrator is not properly implemented and tested (ensembles.cc:403-405)");
   if (g != Integrator::OPEN_DYNAMICS_ENGINE)
-    throw egs::Error(EGS_ERR_UNSUPPORTED, "only Integrator::OPEN_DYNAMICS_ENGINE is on the accelerated path");
+    throw egs::Error(EGS_ERR_UNSUPPORTED,
+                     "Integrator::EXPLICIT_EULER panics in the reference (ComputeJDotV_Joints, ensembles.cc:94-97); "
+                     "only Integrator::OPEN_DYNAMICS_ENGINE completes a step");
   if (StepOnDevice(dt)) return;   // collide -> solve -> integrate in one resident pipeline
   const VectorXd v = GetVelocities();
   if (detect_contacts) UpdateContacts();
