@@ -31,9 +31,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace egs {
@@ -499,6 +502,159 @@ __global__ void __launch_bounds__(1024) murty_check_kernel(int n, const double *
   if (threadIdx.x == 0) {
     rec->first_offender = s_first; rec->out_of_bounds = s_oob; rec->w_bad = s_wbad; rec->pad = 0;
     rec->resid2 = s_res[0]; rec->goodness = s_good[0];
+  }
+}
+
+// ---- the pivot loop's state lives on the device ----------------------------------------------------------
+// Round 2's loop downloaded x and w, chose the flips on the host and uploaded S, C and the index list again: seven
+// small pageable copies per pivot, ~0.1 ms of the 0.37 ms a pivot of the N = 2048 problem took.  Now the host sees one
+// 64-byte record per pivot (written straight into pinned host memory) and everything else stays where it is:
+//   murty_init_kernel     S = 1, C = lo, x = 0, w = r = -b (lcp.cc:184-185), best-iterate memory
+//   murty_prep_kernel     x(!S) = C and b_eff = b - A(:, !S) x(!S)
+//   murty_resid_kernel    r = A x - b, w = S ? 0 : r (lcp.cc:219-223)
+//   murty_advance_kernel  CheckMurtySolution (lcp.cc:20-103) + best-iterate memory (lcp.cc:125-137) + the flips of the
+//                         NEXT pivot (single index, lcp.cc:36-62, or the block rule) + the ascending index list of S
+struct MurtyStep {        // one per pivot, read by the host after the synchronisation
+  int first_offender;     // lowest index that must flip, or INT_MAX
+  int out_of_bounds;      // any x < lo or x > hi            (lcp.cc:66)
+  int w_bad;              // any w < 0 at x == lo or w > 0 at x == hi  (lcp.cc:72-76)
+  int fail;               // a factorisation met a non-positive pivot
+  double resid2;          // || A x - (b + w) ||^2           (lcp.cc:81-83)
+  double goodness;        // sum of the non-positive x and w (lcp.cc:107-113)
+  int ns;                 // |S| after the flips: the size of the next pivot's system
+  int ninf;               // number of infeasible indexes before the flips
+  int flipped;
+  int pad;
+};
+struct MurtyState {       // block-rule and best-iterate memory, device resident
+  int best_ninf, patience;
+  double best_good;
+  int have_best, pad;
+};
+
+__global__ void murty_init_kernel(int n, const double *b, const double *lo, uint8_t *S, double *Cb, double *x, double *w,
+                                  double *r, double *bx, double *bw, MurtyState *st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { st->best_ninf = n + 1; st->patience = 10; st->best_good = 0.0; st->have_best = 0; st->pad = 0; }
+  if (i < n) {
+    const double nb = -b[i];
+    S[i] = 1; Cb[i] = lo[i]; x[i] = 0.0; w[i] = nb; r[i] = nb; bx[i] = 0.0; bw[i] = nb;
+  }
+}
+
+// one wavefront per row: beff = b - A xc (box problems; the reference's own loop drops the term, lcp.cc:199-216),
+// x = xc, xc = S ? 0 : C
+__global__ void __launch_bounds__(256) murty_prep_kernel(const double *M, int n, const double *b, const uint8_t *S,
+                                                         const double *Cb, int box_fix, double *beff, double *x) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double s = 0.0;
+  if (box_fix) {
+    for (int c = lane; c < n; c += 64) s = __builtin_fma(M[(size_t)row * n + c], S[c] ? 0.0 : Cb[c], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  }
+  if (lane == 0) {
+    beff[row] = box_fix ? -(s - b[row]) : b[row];
+    x[row] = S[row] ? 0.0 : Cb[row];
+  }
+}
+
+__global__ void __launch_bounds__(256) murty_resid_kernel(const double *M, int n, const double *x, const double *b,
+                                                          const uint8_t *S, double *r, double *w) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double s = 0.0;
+  for (int c = lane; c < n; c += 64) s = __builtin_fma(M[(size_t)row * n + c], x[c], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) {
+    const double rr = s - b[row];
+    r[row] = rr;
+    w[row] = S[row] ? 0.0 : rr;
+  }
+}
+
+// mode 0: check only; 1: flip the first offender (the reference's rule); 2: the block rule.  Single workgroup.
+__global__ void __launch_bounds__(1024) murty_advance_kernel(int n, const double *x, const double *w, const double *r, uint8_t *S,
+                                                             double *Cb, const double *lo, const double *hi, int mode, double tol,
+                                                             int keep_best, MurtyState *st, double *bx, double *bw, int *idx,
+                                                             const int *fail_a, const int *fail_b, MurtyStep *out) {
+  __shared__ int s_first, s_last, s_ninf, s_oob, s_wbad, s_improved, s_all, s_flip, s_flipped;
+  __shared__ double s_res[1024], s_good[1024];
+  __shared__ int s_scan[1024];
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_first = 0x7fffffff; s_last = -1; s_ninf = 0; s_oob = 0; s_wbad = 0; s_flipped = 0; }
+  __syncthreads();
+  auto offender = [&](int i, double xi, double wi) {
+    if (S[i]) return (xi < lo[i]) || (xi > hi[i]);
+    return (Cb[i] == lo[i] && wi < 0) || (Cb[i] == hi[i] && wi > 0);
+  };
+  double res = 0.0, good = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double xi = x[i], wi = w[i];
+    if (offender(i, xi, wi)) { atomicMin(&s_first, i); atomicMax(&s_last, i); atomicAdd(&s_ninf, 1); }
+    if (xi < lo[i] || xi > hi[i]) s_oob = 1;
+    if ((xi == lo[i] && wi < 0) || (xi == hi[i] && wi > 0)) s_wbad = 1;
+    const double d = r[i] - wi;   // (A x - b) - w
+    res += d * d;
+    if (!(xi > 0)) good += xi;
+    if (!(wi > 0)) good += wi;
+  }
+  s_res[tid] = res; s_good[tid] = good;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if (tid < k) { s_res[tid] += s_res[tid + k]; s_good[tid] += s_good[tid + k]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool solution = s_first == 0x7fffffff && !s_oob && !s_wbad && sqrt(s_res[0]) <= tol;
+    s_improved = keep_best && (!st->have_best || s_good[0] > st->best_good);
+    if (s_improved) { st->best_good = s_good[0]; st->have_best = 1; }
+    bool all = true;
+    int flip = 0;
+    if (mode != 0 && !solution && s_first != 0x7fffffff) {
+      flip = 1;
+      if (mode == 2) {      // every infeasible index while their number keeps falling, else the largest one
+        if (s_ninf < st->best_ninf) { st->best_ninf = s_ninf; st->patience = 10; }
+        else if (st->patience > 0) --st->patience;
+        else all = false;
+      }
+    }
+    s_flip = flip; s_all = all ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_improved) for (int i = tid; i < n; i += 1024) { bx[i] = x[i]; bw[i] = w[i]; }
+  if (s_flip) {
+    const int one = (mode == 1) ? s_first : (s_all ? -1 : s_last);
+    for (int i = tid; i < n; i += 1024) {
+      const double xi = x[i];
+      const bool mine = one >= 0 ? (i == one) : offender(i, xi, w[i]);
+      if (mine) {
+        if (S[i]) { S[i] = 0; Cb[i] = (xi < lo[i]) ? lo[i] : hi[i]; }   // lcp.cc:36-62
+        else S[i] = 1;
+        atomicAdd(&s_flipped, 1);
+      }
+    }
+  }
+  __syncthreads();
+  // the ascending index list of S: thread t owns a run of consecutive indexes
+  const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
+  int cnt = 0;
+  for (int i = i0; i < i1; ++i) cnt += S[i] ? 1 : 0;
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (int k = 1; k < 1024; k <<= 1) {
+    const int v = tid >= k ? s_scan[tid - k] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = s_scan[tid] - cnt;
+  for (int i = i0; i < i1; ++i) if (S[i]) idx[pos++] = i;
+  if (tid == 0) {
+    out->first_offender = s_first; out->out_of_bounds = s_oob; out->w_bad = s_wbad;
+    out->fail = (fail_a ? *fail_a : 0) | (fail_b ? *fail_b : 0);
+    out->resid2 = s_res[0]; out->goodness = s_good[0];
+    out->ns = s_scan[1023]; out->ninf = s_ninf; out->flipped = s_flipped; out->pad = 0;
   }
 }
 
@@ -984,9 +1140,34 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, doub
 // safeguard that guarantees termination.  Same unique solution for SPD A, in
 // tens of factorisations instead of hundreds -- and no min(1000, 2^n) cap, which
 // the reference's single-index rule exhausts for n >~ 600.
+// One pinned (host-coherent) record per host thread: murty_advance_kernel writes it, the host reads it after the sync.
+MurtyStep *pinned_step() {
+  struct Holder {
+    MurtyStep *p = nullptr;
+    ~Holder() { if (p) (void)hipHostFree(p); }
+  };
+  thread_local Holder h;
+  if (!h.p) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h.p), sizeof(MurtyStep), hipHostMallocDefault));
+  return h.p;
+}
+
+struct HostWords { unsigned long long sym[2]; int fail; int pad; };   // pinned landing area of the deferred checks
+HostWords *pinned_words() {
+  struct Holder {
+    HostWords *p = nullptr;
+    ~Holder() { if (p) (void)hipHostFree(p); }
+  };
+  thread_local Holder h;
+  if (!h.p) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h.p), sizeof(HostWords), hipHostMallocDefault));
+  return h.p;
+}
+
+// extra_fail: a device flag of the caller's own factorisation, folded into the record's `fail`; after_first_sync: run
+// once after the first synchronisation (the caller's deferred checks ride on it instead of synchronising themselves).
 bool murty_device(hipStream_t s, int n, const double *dA, const double *db, const std::vector<double> &lo,
                   const std::vector<double> &hi, bool box_fix, bool block, int max_pivots, double max_seconds, double *dx,
-                  double *dw, int *pivots_out, std::string *msg) {
+                  double *dw, int *pivots_out, std::string *msg, const int *extra_fail = nullptr,
+                  const std::function<void()> *after_first_sync = nullptr) {
   const auto t_start = std::chrono::steady_clock::now();
   for (int i = 0; i < n; ++i)   // lcp.cc:161-164; the box variant also admits hi == 0 (toolkit/lcp.h:129)
     if (!(lo[i] < hi[i]) || !(lo[i] <= 0) || !(box_fix ? hi[i] >= 0 : hi[i] > 0)) { if (msg) *msg = "bounds must satisfy lo <= 0 < hi (lcp.cc:161-164)"; return false; }
@@ -1014,138 +1195,74 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     return res.solved != 0;
   }
   const int npad_max = (n + NB - 1) / NB * NB;
-  Buf<double> T((size_t)(npad_max + 1) * npad_max), lo_d(n), hi_d(n), Cb(n), xc(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
+  Buf<double> T((size_t)(npad_max + 1) * npad_max), lohi_d(2 * (size_t)n), Cb(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
   Buf<uint8_t> S_d(n);
   Buf<int> idx_d(n), fail_d(1);
-  Buf<MurtyRecord> rec_d(1);
-  std::vector<uint8_t> S(n, 1);
-  std::vector<double> Cv(lo);
-  std::vector<int> idx(n);
-  HIPCHK(hipMemcpyAsync(lo_d.p, lo.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(hi_d.p, hi.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  Buf<MurtyState> st_d(1);
+  const double *lo_d = lohi_d.p, *hi_d = lohi_d.p + n;
+  MurtyStep *rec = pinned_step();
+  {
+    std::vector<double> lohi(2 * (size_t)n);
+    std::copy(lo.begin(), lo.end(), lohi.begin());
+    std::copy(hi.begin(), hi.end(), lohi.begin() + n);
+    HIPCHK(hipMemcpyAsync(lohi_d.p, lohi.data(), 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  }
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
-  // x = 0, w = -b, r = A x - b = -b   (lcp.cc:184-185)
-  HIPCHK(hipMemsetAsync(dx, 0, n * sizeof(double), s));
-  hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, dw);
-  hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, r.p);
-  HIPCHK(hipMemcpyAsync(bx.p, dx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(bw.p, dw, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  double best_good = 0;
-  bool have_best_good = false;
-  auto upload_state = [&]() {
-    HIPCHK(hipMemcpyAsync(S_d.p, S.data(), n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(Cb.p, Cv.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
-  };
-  std::vector<double> xh(n), wh(n);
-  auto check = [&](const double *xx, const double *ww, const double *rr, MurtyRecord *out) {
-    hipLaunchKernelGGL(murty_check_kernel, dim3(1), dim3(1024), 0, s, n, xx, ww, rr, S_d.p, Cb.p, lo_d.p, hi_d.p, rec_d.p);
-    HIPCHK(hipMemcpyAsync(out, rec_d.p, sizeof(MurtyRecord), hipMemcpyDeviceToHost, s));
-    if (block) {   // the block rule looks at every x and w: they ride on the same synchronisation as the record
-      HIPCHK(hipMemcpyAsync(xh.data(), xx, n * sizeof(double), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(wh.data(), ww, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
+  // x = 0, w = -b, r = A x - b = -b   (lcp.cc:184-185); S = everything, C = lo
+  hipLaunchKernelGGL(murty_init_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, lo_d, S_d.p, Cb.p, dx, dw, r.p, bx.p, bw.p, st_d.p);
+  const int flip_mode = block ? 2 : 1;
+  // check the iterate on the device, flip for the next pivot there too, and read the 64-byte record
+  auto advance = [&](int mode, double tol, int keep_best) {
+    hipLaunchKernelGGL(murty_advance_kernel, dim3(1), dim3(1024), 0, s, n, dx, dw, r.p, S_d.p, Cb.p, lo_d, hi_d, mode, tol, keep_best,
+                       st_d.p, bx.p, bw.p, idx_d.p, fail_d.p, extra_fail, rec);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
   };
-  auto is_solution = [&](const MurtyRecord &rc, double tol) {
-    return rc.first_offender == 0x7fffffff && !rc.out_of_bounds && !rc.w_bad && std::sqrt(rc.resid2) <= tol;
+  auto is_solution = [&](double tol) {
+    return rec->first_offender == 0x7fffffff && !rec->out_of_bounds && !rec->w_bad && std::sqrt(rec->resid2) <= tol;
   };
-  auto apply_flip = [&](const MurtyRecord &rc, const std::vector<double> &xh) {
-    const int i = rc.first_offender;  // lcp.cc:36-62
-    if (S[i]) { S[i] = 0; Cv[i] = (xh[i] < lo[i]) ? lo[i] : hi[i]; }
-    else S[i] = 1;
-  };
-  upload_state();
-  MurtyRecord rc;
   int iter = 0, pivots = 0;
-  int best_ninf = n + 1, patience = 10;   // block rule state
-  bool force = box_fix, solved = false;
-  {  // goodness of the start iterate for the best-solution memory
-    check(dx, dw, r.p, &rc);
-    best_good = rc.goodness; have_best_good = true;
-  }
-  bool timed_out = false;
-  while (iter < max_iterations) {
+  bool force = box_fix, solved = false, timed_out = false;
+  // the start iterate: its goodness opens the best-solution memory; a box problem solves once before the first flip,
+  // the reference's loop (lcp.cc:196-198) checks and flips first
+  advance(force ? 0 : flip_mode, 1e-9, 1);
+  if (after_first_sync) (*after_first_sync)();
+  const bool trace = std::getenv("EGS_DENSE_TRACE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  while (iter < max_iterations && !rec->fail) {
     if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > max_seconds) {
       timed_out = true;   // lcp::Settings::max_time (toolkit/lcp.h:166-167)
       break;
     }
-    if (!force) {
-      if (is_solution(rc, 1e-9)) { solved = true; break; }
-      if (rc.first_offender == 0x7fffffff) {
-        // no index to flip but not a solution (residual / sign checks failed):
-        // the reference recomputes with unchanged S; do the same.
-      } else if (block) {
-        std::vector<int> bad;      // xh, wh came with the record (check)
-        for (int i = 0; i < n; ++i) {
-          const bool off = S[i] ? (xh[i] < lo[i] || xh[i] > hi[i])
-                                : ((Cv[i] == lo[i] && wh[i] < 0) || (Cv[i] == hi[i] && wh[i] > 0));
-          if (off) bad.push_back(i);
-        }
-        const int ninf = (int)bad.size();
-        bool all = true;
-        if (ninf < best_ninf) { best_ninf = ninf; patience = 10; }
-        else if (patience > 0) --patience;
-        else all = false;
-        auto flip = [&](int i) {
-          if (S[i]) { S[i] = 0; Cv[i] = (xh[i] < lo[i]) ? lo[i] : hi[i]; }
-          else S[i] = 1;
-        };
-        if (all) for (int i : bad) flip(i);
-        else flip(bad.back());
-        upload_state();
-      } else {
-        if (S[rc.first_offender]) HIPCHK(hipMemcpyAsync(xh.data(), dx, n * sizeof(double), hipMemcpyDeviceToHost, s)), HIPCHK(hipStreamSynchronize(s));
-        apply_flip(rc, xh);
-        upload_state();
-      }
-    }
+    if (!force && is_solution(1e-9)) { solved = true; break; }
+    // (no index to flip but not a solution -- residual / sign checks failed: the reference recomputes with unchanged S,
+    //  and so does this)
     force = false;
     // new candidate: x(S) = A(S,S)^-1 (b(S) [- A(S,!S) x(!S)])   lcp.cc:199-216
-    int ns = 0;
-    for (int i = 0; i < n; ++i) if (S[i]) idx[ns++] = i;
+    const int ns = rec->ns;
     const int nspad = (ns + NB - 1) / NB * NB;
-    hipLaunchKernelGGL(clamp_x_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, Cb.p, xc.p);
-    if (box_fix) {
-      // beff = b - A xc  ->  computed as -(A xc - b)
-      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, xc.p, db, beff.p);
-      hipLaunchKernelGGL(negate_kernel, dim3(grid1(n)), dim3(256), 0, s, n, beff.p, beff.p);
-    } else {
-      HIPCHK(hipMemcpyAsync(beff.p, db, n * sizeof(double), hipMemcpyDeviceToDevice, s));  // reference omits A(S,!S)x(!S)
-    }
-    HIPCHK(hipMemcpyAsync(dx, xc.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(murty_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, db, S_d.p, Cb.p, box_fix ? 1 : 0, beff.p, dx);
     if (ns > 0) {
-      HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), ns * sizeof(int), hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
                          nspad, beff.p, T.p);
       factor(s, T.p, nspad, nspad + 1, nspad, fail_d.p, dinv.p);
       hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, nspad, nspad, nspad, ns, idx_d.p, dx, xs.p,
                          dinv.p);
     }
-    // r = A x - b; w(!S) = r (box_fix) or A(!S,S) x(S) - b(!S) (reference, lcp.cc:219-221)
-    if (box_fix) {
-      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
-      hipLaunchKernelGGL(set_w_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, r.p, dw);
-    } else {
-      // reference: w uses x(S) only; x(!S) = lo = 0 here so A x(S-only) == A x
-      hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
-      hipLaunchKernelGGL(set_w_kernel, dim3(grid1(n)), dim3(256), 0, s, n, S_d.p, r.p, dw);
-    }
+    // r = A x - b; w(!S) = r.  (The reference, lcp.cc:219-221, uses x(S) only: x(!S) = lo = 0 there, so A x(S) == A x.)
+    hipLaunchKernelGGL(murty_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, S_d.p, r.p, dw);
     ++pivots;
-    check(dx, dw, r.p, &rc);
-    // lcp.cc:125-137: keep the best iterate by "goodness"
-    if (!have_best_good || rc.goodness > best_good) {
-      best_good = rc.goodness; have_best_good = true;
-      HIPCHK(hipMemcpyAsync(bx.p, dx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-      HIPCHK(hipMemcpyAsync(bw.p, dw, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    advance(flip_mode, 1e-9, 1);     // lcp.cc:125-137: the best iterate by "goodness" is kept by the kernel
+    if (trace) {
+      const auto t_now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d, %.3f ms\n", pivots, ns, n, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+      t_prev = t_now;
     }
     ++iter;
   }
-  if (!solved && iter < max_iterations && !timed_out) solved = is_solution(rc, 1e-9);
+  if (!solved && iter < max_iterations && !timed_out && !rec->fail) solved = is_solution(1e-9);
   *pivots_out = pivots;
-  int fail = 0;
-  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (fail) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
+  if (rec->fail) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
   if (solved) return true;  // x, w hold the solution iterate (== best, see lcp.cc:241)
   // capped: return the best-seen iterate and re-check it with the looser 1e-8 (lcp.cc:241-246)
   if (!box_fix && !block) {
@@ -1153,8 +1270,8 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     HIPCHK(hipMemcpyAsync(dw, bw.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   hipLaunchKernelGGL(gemv_minus_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, r.p);
-  check(dx, dw, r.p, &rc);
-  const bool ok = is_solution(rc, 1e-8);
+  advance(0, 1e-8, 0);
+  const bool ok = is_solution(1e-8);
   if (!ok && msg) *msg = "MurtyPrincipalPivot: iteration cap reached without a sensible solution (lcp.cc:250-252)";
   return ok;
 }
@@ -1351,64 +1468,77 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
                                     double max_seconds, double *x, double *w, double *dx_out, int *pivots, std::string *msg) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
+  const auto t_dev0 = std::chrono::steady_clock::now();
   std::vector<int> E, I;
   for (int i = 0; i < N; ++i) (C[i] ? E : I).push_back(i);
   const int ne = (int)E.size(), ni = (int)I.size();
   const int nepad = (ne + NB - 1) / NB * NB;
   const int ld = nepad + ni, rows = nepad + ni + 1;
   Buf<double> T((size_t)rows * (ld > 0 ? ld : 1)), lhs((size_t)ni * ni), rhs(ni), xi(ni), wi(ni), xe(ne), xs(nepad), dinv((size_t)nepad * NB);
-  Buf<int> dE(ne), dI(ni), fail_d(1);
+  Buf<int> dEI(N), fail_d(1);
+  int *const dE_p = dEI.p, *const dI_p = dEI.p + ne;
   struct { const double *p; } dA{dA_in}, db{db_in};
-  if (ne) HIPCHK(hipMemcpyAsync(dE.p, E.data(), ne * sizeof(int), hipMemcpyHostToDevice, s));
-  if (ni) HIPCHK(hipMemcpyAsync(dI.p, I.data(), ni * sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
-  {  // A must be symmetric: the factorisations read its lower triangle only
-    Buf<unsigned long long> sym_d(2);
-    unsigned long long sym_h[2] = {0, 0};
-    HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(symmetry_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, s, dA.p, N, sym_d.p);
-    HIPCHK(hipMemcpyAsync(sym_h, sym_d.p, sizeof sym_h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    double amax, asym;
-    std::memcpy(&amax, &sym_h[0], sizeof amax);
-    std::memcpy(&asym, &sym_h[1], sizeof asym);
-    if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
+  {
+    std::vector<int> EI(E);
+    EI.insert(EI.end(), I.begin(), I.end());
+    HIPCHK(hipMemcpyAsync(dEI.p, EI.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, s));
   }
+  HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
+  // A must be symmetric: the factorisations read its lower triangle only.  The verdict (and the Schur factorisation's
+  // failure flag) is read at the first synchronisation the pivot loop makes anyway, not at one of its own.
+  Buf<unsigned long long> sym_d(2);
+  HostWords *host = pinned_words();
+  HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(symmetry_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, s, dA.p, N, sym_d.p);
+  HIPCHK(hipMemcpyAsync(host->sym, sym_d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   // Schur stage: factor the E columns of [A_ee A_ei; A_ie A_ii; b^T]   (lcp.cc:286-294)
-  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE.p, ne, nepad, dI.p, ni, T.p, 0);
+  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE_p, ne, nepad, dI_p, ni, T.p, 0);
   factor(s, T.p, ld, rows, nepad, fail_d.p, dinv.p);
   if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
-  int fail = 0;
-  HIPCHK(hipMemcpyAsync(&fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (fail) { if (msg) *msg = "A_ee is not positive definite"; return false; }
+  HIPCHK(hipMemcpyAsync(&host->fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  bool schur_failed = false;
+  const std::function<void()> deferred = [&]() {     // after any synchronisation that follows the copies above
+    double amax, asym;
+    std::memcpy(&amax, &host->sym[0], sizeof amax);
+    std::memcpy(&asym, &host->sym[1], sizeof asym);
+    if (asym > 1e-10 * std::max(amax, 1e-300)) throw std::invalid_argument("A must be symmetric (J M^-1 J^T + cfm I is)");
+    if (host->fail) schur_failed = true;
+    if (std::getenv("EGS_DENSE_TRACE"))
+      std::fprintf(stderr, "dense trace schur: ne %d ni %d, symmetry + factor + first check %.3f ms\n", ne, ni,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count());
+  };
+  if (ni == 0) { HIPCHK(hipStreamSynchronize(s)); deferred(); }
   // Murty on the inequality part; the reference calls the no-bounds overload (lcp.cc:298)
   std::vector<double> l2(ni), h2(ni);
   for (int k = 0; k < ni; ++k) { l2[k] = use_bounds ? lo[I[k]] : 0.0; h2[k] = use_bounds ? hi[I[k]] : std::numeric_limits<double>::infinity(); }
   int piv = 0;
-  const bool ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, max_pivots, max_seconds, xi.p, wi.p, &piv, msg);
+  bool deferred_ran = ni == 0;
+  const std::function<void()> once = [&]() { if (!deferred_ran) { deferred_ran = true; deferred(); } };
+  bool ok = true;
+  if (!schur_failed) ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, max_pivots, max_seconds, xi.p, wi.p, &piv, msg, fail_d.p, &once);
+  once();     // (paths of the pivot loop that return without its first synchronisation hook have synchronised all the same)
+  if (schur_failed) { if (msg) *msg = "A_ee is not positive definite"; return false; }
   if (pivots) *pivots = piv;
   if (!ok) return false;
   // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)
-  std::vector<double> xih(ni), wih(ni), xeh(ne);
+  Buf<double> xw((size_t)2 * N);      // x and w in the caller's order: one copy back
+  std::vector<double> xwh((size_t)2 * N);
+  HIPCHK(hipMemsetAsync(xw.p, 0, (size_t)2 * N * sizeof(double), s));     // w = 0 on the equality rows, lcp.cc:332-333
   if (ne) {
     hipLaunchKernelGGL(xe_rhs_kernel, dim3(nepad / NB), dim3(1024), 0, s, T.p, nepad, ni, xi.p);
     hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p,
                        dinv.p);
-    HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ne)), dim3(256), 0, s, ne, dE_p, xe.p, xw.p);
   }
   if (ni) {
-    HIPCHK(hipMemcpyAsync(xih.data(), xi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(wih.data(), wi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ni)), dim3(256), 0, s, ni, dI_p, xi.p, xw.p);
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ni)), dim3(256), 0, s, ni, dI_p, wi.p, xw.p + N);
   }
-  if (dx_out) {   // the solution stays on the device too (no host round trip for the caller's next kernel)
-    if (ne) hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ne)), dim3(256), 0, s, ne, dE.p, xe.p, dx_out);
-    if (ni) hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ni)), dim3(256), 0, s, ni, dI.p, xi.p, dx_out);
-  }
+  HIPCHK(hipMemcpyAsync(xwh.data(), xw.p, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (dx_out) HIPCHK(hipMemcpyAsync(dx_out, xw.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));   // stays on the device too
   HIPCHK(hipStreamSynchronize(s));
-  if (w) for (int i = 0; i < N; ++i) w[i] = 0.0;  // lcp.cc:332-333
-  if (x) for (int k = 0; k < ne; ++k) x[E[k]] = xeh[k];
-  for (int k = 0; k < ni; ++k) { if (x) x[I[k]] = xih[k]; if (w) w[I[k]] = wih[k]; }
+  if (x) std::memcpy(x, xwh.data(), (size_t)N * sizeof(double));
+  if (w) std::memcpy(w, xwh.data() + N, (size_t)N * sizeof(double));
   return true;
 }
 
