@@ -80,68 +80,173 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Diagonal block: L11 = chol(T[k0.., k0..+64)) and its inverse, one workgroup of
-// five wavefronts in lock step (one barrier per column), everything in registers:
-//   wavefronts 0..3, lane i = row i of the block, wavefront w holding the columns
-//     k = w mod 4 (16 registers): right-looking Cholesky; the owner of column j
-//     scales it by 1/sqrt(pivot) and publishes it in LDS, then every wavefront
-//     updates ITS columns with it (16 - j/4 fused multiply-adds instead of 63 - j:
-//     the column step is the pivot's own latency chain -- broadcast read, fma,
-//     readlane, 1/sqrt refinement, scale, publish, barrier -- and little else);
-//     a finished column goes to memory at once, so its register may be clobbered;
-//   wavefront 4, lane c = column c of L11^-1: forward substitution L X = I fed
-//     by those columns (row j of the inverse is complete after step j).
-// The inverse turns the panel's triangular solve and the diagonal steps of the
-// back substitution into matrix products (chol_trsm_kernel, back_solve_kernel).
-__global__ void __launch_bounds__(320) chol_diag_kernel(const double *T, double *Tout, int ld, int k0, double *inv, int *fail) {
-  __shared__ __attribute__((aligned(16))) double sCol[2][NB];
-  __shared__ double sRinv[2];
+// ---- the diagonal tile ------------------------------------------------------------------------------------
+// L11 = chol(tile) and its inverse for a 64 x 64 tile staged in LDS, one workgroup of five wavefronts.  This is the
+// latency chain of the whole factorisation (one tile per 64 columns, nothing else can start before it ends), so it is
+// built for few dependent steps rather than for throughput (tools/diag_bench.hip times the variants: 23.4 us for the
+// round-2 routine -- one barrier per column, the inverse accumulated by a fifth wavefront with 63 - j multiply-adds
+// per column -- against 12.9 us for this one):
+//   * wavefronts 0..3, lane i = row i; wavefront w holds the four-column groups g = 4 m + w (16 registers).  The
+//     owner of group g reads the 4 x 4 diagonal mini-block out of its lanes once (readlane -> scalar registers),
+//     factors it redundantly in every lane and solves its own row against it: no cross-lane traffic inside the four
+//     columns.  The four columns go to LDS (column-major sL, every column in its own place: no double buffer), ONE
+//     barrier per group, and every wavefront applies the rank-4 update to the groups it holds -- the factored ones too
+//     (dead registers; the code stays free of wavefront-dependent branches).  Entries above the diagonal are scratch:
+//     nothing masks them and nothing reads them.
+//   * wavefront 4, lane c < 16 = column c of the inverse of the current 16 x 16 diagonal block: forward substitution
+//     row by row as the columns appear (15 - r multiply-adds per row, in the shadow of the column chain).
+//   * afterwards the rest of the inverse by products on the fp64 matrix cores: X(2p+1, 2p) = -X(2p+1, 2p+1) L(2p+1, 2p)
+//     X(2p, 2p) for the two 32 x 32 diagonal blocks, then the 32 x 32 block below them the same way.
+//   * L (lower triangle) and the inverse (all of it: zero above the diagonal) go to memory at the end, rows coalesced.
+// The inverse turns the panel's triangular solve and the diagonal steps of the back substitution into matrix
+// products (chol_trsm_kernel, chol_panel_kernel, back_solve_kernel).
+constexpr int kTileLs = NB + 2;      // column stride of sL / row stride of sX (doubles)
+constexpr int kTileQs = 34;          // row stride of the 32 x 32 scratch
+constexpr int kTileLdsDoubles = 2 * NB * kTileLs + 32 * kTileQs + NB;      // sL, sX, sQ, sRv
+
+__device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// sB: the tile, row-major with row stride ldb.  sL, sX: NB * kTileLs doubles each; sQ: 32 * kTileQs; sRv: NB.
+// Tout / inv: where L (row stride ld, tile origin already applied) and the inverse (64 x 64, dense) go.
+__device__ __forceinline__ void chol_diag_tile(const double *sB, int ldb, double *sL, double *sX, double *sQ, double *sRv, double *Tout,
+                                               int ld, double *inv, int *fail) {
+  constexpr int GW = 4, NG = NB / GW, MG = NG / 4, LS = kTileLs, XS = kTileLs, QS = kTileQs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < NB * XS; i += blockDim.x) sX[i] = 0.0;      // the inverse is zero above its diagonal blocks
   if (wave < 4) {
-    double a[NB / 4];
+    double a[MG][GW];
 #pragma unroll
-    for (int m = 0; m < NB / 4; ++m) {
-      const int c = 4 * m + wave;
-      a[m] = (c <= lane) ? T[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
-    }
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+      for (int q = 0; q < GW; ++q) a[m][q] = sB[lane * ldb + GW * (4 * m + wave) + q];
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int mo = j >> 2;
-      if (wave == (j & 3)) {   // this wavefront owns column j, final since the update of step j - 1
-        double d = readlane_f64(a[mo], j);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double rinv = rsqrt_refined(d);
-        const double l = (lane >= j) ? a[mo] * rinv : 0.0;
-        sCol[j & 1][lane] = l;
-        if (lane == j) sRinv[j & 1] = rinv;
-        if (lane >= j) Tout[(size_t)(k0 + lane) * ld + k0 + j] = l;
+    for (int g = 0; g < NG; ++g) {
+      const int mo = g >> 2, c0 = GW * g;
+      if (wave == (g & 3)) {
+        // the mini-block's lower triangle, m[r][c] from lane c0 + r
+        const double m00 = readlane_f64(a[mo][0], c0);
+        const double m10 = readlane_f64(a[mo][0], c0 + 1), m11 = readlane_f64(a[mo][1], c0 + 1);
+        const double m20 = readlane_f64(a[mo][0], c0 + 2), m21 = readlane_f64(a[mo][1], c0 + 2), m22 = readlane_f64(a[mo][2], c0 + 2);
+        const double m30 = readlane_f64(a[mo][0], c0 + 3), m31 = readlane_f64(a[mo][1], c0 + 3), m32 = readlane_f64(a[mo][2], c0 + 3),
+                     m33 = readlane_f64(a[mo][3], c0 + 3);
+        const double r0 = rsqrt_refined(m00);
+        const double x0 = a[mo][0] * r0;
+        const double l10 = m10 * r0, l20 = m20 * r0, l30 = m30 * r0;
+        const double d1 = __builtin_fma(-l10, l10, m11);
+        const double r1 = rsqrt_refined(d1);
+        const double x1 = __builtin_fma(-x0, l10, a[mo][1]) * r1;
+        const double l21 = __builtin_fma(-l20, l10, m21) * r1, l31 = __builtin_fma(-l30, l10, m31) * r1;
+        const double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
+        const double r2 = rsqrt_refined(d2);
+        const double x2 = __builtin_fma(-x1, l21, __builtin_fma(-x0, l20, a[mo][2])) * r2;
+        const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * r2;
+        const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
+        const double r3 = rsqrt_refined(d3);
+        const double x3 = __builtin_fma(-x2, l32, __builtin_fma(-x1, l31, __builtin_fma(-x0, l30, a[mo][3]))) * r3;
+        bad |= !(m00 > 0.0) | !(d1 > 0.0) | !(d2 > 0.0) | !(d3 > 0.0);
+        sL[(c0 + 0) * LS + lane] = x0; sL[(c0 + 1) * LS + lane] = x1; sL[(c0 + 2) * LS + lane] = x2; sL[(c0 + 3) * LS + lane] = x3;
+        if (lane == 0) { sRv[c0] = r0; sRv[c0 + 1] = r1; sRv[c0 + 2] = r2; sRv[c0 + 3] = r3; }
       }
       lds_barrier();
-      if (j + 1 < NB) {
-        const double lrow = sCol[j & 1][lane];           // this row's entry of column j
-        // columns 4 m + wave of the groups m >= j / 4: those <= j are finished and stored, the rest get step j
+      if (g + 1 < NG) {
+        double lrow[GW];
 #pragma unroll
-        for (int m = mo; m < NB / 4; ++m) a[m] = __builtin_fma(-lrow, sCol[j & 1][4 * m + wave], a[m]);
+        for (int q = 0; q < GW; ++q) lrow[q] = sL[(c0 + q) * LS + lane];
+#pragma unroll
+        for (int m = mo; m < MG; ++m) {
+          const int cg = GW * (4 * m + wave);
+#pragma unroll
+          for (int q2 = 0; q2 < GW; ++q2) {
+            double acc = a[m][q2];
+#pragma unroll
+            for (int q = 0; q < GW; ++q) acc = __builtin_fma(-lrow[q], sL[(c0 + q) * LS + cg + q2], acc);
+            a[m][q2] = acc;
+          }
+        }
       }
     }
     if (bad && lane == 0) atomicOr(fail, 1);
   } else {
-    double a[NB];
+    double acc[16];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int g = 0; g < NG; ++g) {
       lds_barrier();
-      const double xj = (((lane == j) ? 1.0 : 0.0) - a[j]) * sRinv[j & 1];   // lanes c > j: exactly 0
-      inv[j * NB + lane] = xj;
-      double col[NB];
 #pragma unroll
-      for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
+      for (int q = 0; q < GW; ++q) {
+        const int R = GW * g + q, b = R >> 4, r = R & 15;
+        if (r == 0) {
 #pragma unroll
-      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(col[k], xj, a[k]);
+          for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+        }
+        if (lane < 16) {
+          const double x = (((lane == r) ? 1.0 : 0.0) - acc[r]) * sRv[R];      // lanes c > r: exactly 0
+          sX[R * XS + 16 * b + lane] = x;
+#pragma unroll
+          for (int k2 = r + 1; k2 < 16; ++k2) acc[k2] = __builtin_fma(sL[R * LS + 16 * b + k2], x, acc[k2]);
+        }
+      }
     }
   }
+  lds_barrier();
+  // v_mfma_f64_16x16x4_f64 operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; D: col = lane&15, row = (lane>>4) + 4 reg
+  const int li = lane & 15, lk = lane >> 4;
+  if (wave < 2) {      // X(2p+1, 2p) = -X(2p+1, 2p+1) (L(2p+1, 2p) X(2p, 2p)), p = wave
+    const int o = 32 * wave;
+    double4_t P = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) P = mfma_f64(sL[(o + 4 * kk + lk) * LS + o + 16 + li], sX[(o + 4 * kk + lk) * XS + o + li], P);
+    double *sP = sQ + wave * 16 * QS;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sP[(lk + 4 * reg) * QS + li] = P[reg];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    double4_t D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) D = mfma_f64(sX[(o + 16 + li) * XS + o + 16 + 4 * kk + lk], sP[(4 * kk + lk) * QS + li], D);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sX[(o + 16 + lk + 4 * reg) * XS + o + li] = -D[reg];
+  }
+  lds_barrier();
+  // X_BL = -X_BR (L_BL X_TL) on the 32 x 32 blocks, one 16 x 16 tile per wavefront
+  if (wave < 4) {
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t Q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) Q = mfma_f64(sL[(4 * kk + lk) * LS + 32 + 16 * ti + li], sX[(4 * kk + lk) * XS + 16 * tj + li], Q);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sQ[(16 * ti + lk + 4 * reg) * QS + 16 * tj + li] = Q[reg];
+  }
+  lds_barrier();
+  if (wave < 4) {
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) D = mfma_f64(sX[(32 + 16 * ti + li) * XS + 32 + 4 * kk + lk], sQ[(4 * kk + lk) * QS + 16 * tj + li], D);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sX[(32 + 16 * ti + lk + 4 * reg) * XS + 16 * tj + li] = -D[reg];
+  }
+  lds_barrier();
+  for (int i = threadIdx.x; i < NB * NB; i += blockDim.x) {
+    const int r = i >> 6, c = i & 63;
+    inv[i] = sX[r * XS + c];
+    if (c <= r) Tout[(size_t)r * ld + c] = sL[c * LS + r];
+  }
+}
+
+constexpr int kDiagThreads = 320;
+constexpr size_t kDiagLdsBytes = (size_t)(NB * (NB + 2) + kTileLdsDoubles) * sizeof(double);
+
+// The tile at (k0, k0) of T: L to Tout (same place), the inverse to inv.
+__global__ void __launch_bounds__(kDiagThreads) chol_diag_kernel(const double *T, double *Tout, int ld, int k0, double *inv, int *fail) {
+  extern __shared__ __attribute__((aligned(16))) double smem_d[];
+  double *sB = smem_d, *sL = sB + NB * (NB + 2), *sX = sL + NB * kTileLs, *sQ = sX + NB * kTileLs, *sRv = sQ + 32 * kTileQs;
+  for (int i = threadIdx.x; i < NB * NB; i += blockDim.x) {
+    const int r = i >> 6, c = i & 63;
+    sB[r * (NB + 2) + c] = T[(size_t)(k0 + r) * ld + k0 + c];
+  }
+  __syncthreads();
+  chol_diag_tile(sB, NB + 2, sL, sX, sQ, sRv, Tout + (size_t)k0 * ld + k0, ld, inv, fail);
 }
 
 // A 64 x 64 block of doubles from global memory (row stride ld) into LDS (row stride kStageLd) with 16-byte loads, all
@@ -195,9 +300,10 @@ __device__ __forceinline__ void mfma_quadrant(const double *sA, const double *sB
 // Panel below the diagonal block: X = B L11^-T = B (L11^-1)^T on the fp64 matrix
 // cores, X[r][c] = sum_k B[r][k] Linv[c][k].  One workgroup per 64-row slab,
 // each wavefront a 32x32 quadrant; both operands staged in LDS.  B is read from T, X goes to Tout (may be T).
-__global__ void __launch_bounds__(256) chol_trsm_kernel(const double *T, double *Tout, int ld, int nrows, int k0, const double *inv) {
+__global__ void __launch_bounds__(256) chol_trsm_kernel(const double *T, double *Tout, int ld, int nrows, int k0, const double *inv, int ibase, int iend) {
   __shared__ __attribute__((aligned(16))) double sA[NB * kStageLd], sBm[NB * kStageLd];
   const int r0 = k0 + NB + blockIdx.x * NB;
+  if (r0 >= ibase && r0 < iend && r0 - ibase >= k0 + NB) return;      // identity rows that no panel has reached yet (see factor())
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = (wave >> 1) * 32, lc = (wave & 1) * 32;
   const int li = lane & 15, lk = lane >> 4;
@@ -272,12 +378,22 @@ __global__ void __launch_bounds__(256) chol_update_kernel(double *T, int ld, int
 // the 64-row strip L[k-block][0..k) (contiguous rows, coalesced) is subtracted
 // from the remaining right-hand side.
 // x is written to out[map ? map[i] : i] for i < nreal (padding rows dropped).
+// XS_LDS: the running right-hand side lives in LDS (nf <= kBackSolveLdsRows) instead of global scratch -- every block
+// step reads and rewrites it, and a workgroup-visible global round trip costs a microsecond each way.
+constexpr int kBackSolveLdsRows = 16384;
+template <bool XS_LDS>
 __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int ld, int nf, int yrow, int nreal,
-                                                          const int *map, double *out, double *xs /*[nf] scratch*/,
+                                                          const int *map, double *out, double *xs_global /*[nf] scratch*/,
                                                           const double *inv) {
+  extern __shared__ __attribute__((aligned(16))) double xs_lds[];
+  double *xs = XS_LDS ? xs_lds : xs_global;
   __shared__ double sx[NB];
   __shared__ double red[16][NB];
+  __shared__ double redB[1024];
   const int tid = threadIdx.x;
+  // with the right-hand side in LDS nothing a step exchanges goes through memory: a barrier that orders LDS only lets
+  // the loads requested ahead (next strip, next inverse block) stay in flight across it
+  auto step_barrier = [] { if (XS_LDS) lds_barrier(); else __syncthreads(); };
   for (int i = tid; i < nf; i += 1024) xs[i] = T[(size_t)yrow * ld + i];
   __syncthreads();
   // thread (i, part) of the 64 x 16 layout multiplies rows part, part+16, ... of the inverse block;
@@ -290,6 +406,18 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
     for (int q = 0; q < 4; ++q) li[q] = nf >= NB ? Li[(part + 16 * q) * NB + i] : 0.0;
   }
   for (int kb = nf - NB; kb >= 0; kb -= NB) {
+    // The strip L[kb .. kb+64)[0 .. kb) is subtracted from the kb open entries by P threads per column (P rows-parts of
+    // R = 64 / P rows, as many as 1024 threads allow); its entries do not depend on x_k, so they are requested now and
+    // arrive while x_k = L_kk^-T t_k is formed.
+    int P = kb > 0 ? 1024 / kb : 0;
+    P = P >= 16 ? 16 : P >= 8 ? 8 : P >= 4 ? 4 : P >= 2 ? 2 : P;
+    const int R = P ? NB / P : 0;
+    const bool active = P > 0 && tid < P * kb;
+    const int c = active ? tid % kb : 0, rp = active ? tid / kb : 0;
+    double lv[32];
+    const double *strip = T + (size_t)(kb + rp * R) * ld + c;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lv[j] = (active && j < R) ? strip[(size_t)j * ld] : 0.0;
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) s = __builtin_fma(li[q], xs[kb + part + 16 * q], s);   // Linv[r][i] = 0 for i > r
@@ -299,7 +427,7 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
 #pragma unroll
       for (int q = 0; q < 4; ++q) li[q] = Ln[(part + 16 * q) * NB + i];
     }
-    __syncthreads();
+    step_barrier();
     if (tid < NB) {
       double x = 0.0;
 #pragma unroll
@@ -307,16 +435,52 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
       sx[tid] = x;
       xs[kb + tid] = x;
     }
-    __syncthreads();
-    for (int c = tid; c < kb; c += 1024) {
-      double y = xs[c];
+    step_barrier();
+    if (P == 0) continue;      // (kb == 0: nothing left to update; uniform)
+    double u = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if (j < R) u = __builtin_fma(lv[j], sx[rp * R + j], u);
+    if (P == 1) {             // more than 512 open columns: one thread per column, the second half of its 64 rows now
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) lv[j] = strip[(size_t)(32 + j) * ld];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) u = __builtin_fma(lv[j], sx[32 + j], u);
+        xs[c] -= u;
+      }
+      for (int c2 = tid + 1024; c2 < kb; c2 += 1024) {      // (more than 1024 open columns)
+        double y = 0.0;
 #pragma unroll 32
-      for (int r = 0; r < NB; ++r) y = __builtin_fma(-T[(size_t)(kb + r) * ld + c], sx[r], y);
-      xs[c] = y;
+        for (int r = 0; r < NB; ++r) y = __builtin_fma(T[(size_t)(kb + r) * ld + c2], sx[r], y);
+        xs[c2] -= y;
+      }
+    } else {
+      if (active) redB[rp * kb + c] = u;
+      step_barrier();
+      if (tid < kb) {
+        double y = 0.0;
+        for (int p = 0; p < P; ++p) y += redB[p * kb + tid];
+        xs[tid] -= y;
+      }
     }
-    __syncthreads();
+    step_barrier();
   }
   for (int i = tid; i < nreal; i += 1024) out[map ? map[i] : i] = xs[i];
+}
+
+void launch_back_solve(hipStream_t s, const double *T, int ld, int nf, int yrow, int nreal, const int *map, double *out, double *xs,
+                       const double *inv) {
+  if (nf <= kBackSolveLdsRows) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(back_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(kBackSolveLdsRows * sizeof(double))));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(back_solve_kernel<true>, dim3(1), dim3(1024), (size_t)nf * sizeof(double), s, T, ld, nf, yrow, nreal, map, out, xs, inv);
+  } else {
+    hipLaunchKernelGGL(back_solve_kernel<false>, dim3(1), dim3(1024), 0, s, T, ld, nf, yrow, nreal, map, out, xs, inv);
+  }
 }
 
 // max |a_ij| and max |a_ij - a_ji| over i > j (non-negative doubles order like
@@ -391,19 +555,40 @@ __global__ void extract_schur_kernel(const double *T, int nepad, int ni, double 
   }
 }
 
-// Pivot trapezoid: A(S,S) padded with an identity block, b_eff(S) as last row.
+// Pivot trapezoid: A(S,S) padded with an identity block; then nspad identity rows (they become L^-T, see factor());
+// b_eff(S) as last row.
 __global__ void build_pivot_kernel(const double *lhs, int n, const int *S, int ns, int nspad, const double *beff,
-                                   double *T) {
-  const int ld = nspad, rows = nspad + 1;
+                                   double *T, int identity_rows) {
+  const int ld = nspad, ib = identity_rows ? nspad : 0, rows = nspad + ib + 1;
   const size_t total = (size_t)rows * ld;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / ld), c = (int)(idx % ld);
     double v = 0.0;
     if (r < ns) { if (c < ns) v = lhs[(size_t)S[r] * n + S[c]]; }
     else if (r < nspad) v = (c == r) ? 1.0 : 0.0;
+    else if (r < nspad + ib) v = (c == r - nspad) ? 1.0 : 0.0;
     else { if (c < ns) v = beff[S[c]]; }
     T[idx] = v;
   }
+}
+
+// x = L^-T z from the rows the factorisation turned into L^-T (factor(), ibase): x_i = sum_{c >= i} Linvt[i][c] z[c],
+// z = T[zrow][.] = L^-1 b.  One wavefront per row; x goes to out[map ? map[i] : i] for i < nreal.
+__global__ void __launch_bounds__(256) inverse_rows_solve_kernel(const double *T, int ld, int nf, int ibase, int zrow, int nreal,
+                                                                 const int *map, double *out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nreal) return;
+  const double *Li = T + (size_t)(ibase + row) * ld, *z = T + (size_t)zrow * ld;
+  double s0 = 0.0, s1 = 0.0;
+  int c = (row & ~63) + lane;      // whole 64-column groups from the one that holds the diagonal
+  for (; c + 64 < nf; c += 128) {
+    s0 = __builtin_fma(c >= row ? Li[c] : 0.0, z[c], s0);
+    s1 = __builtin_fma(Li[c + 64], z[c + 64], s1);
+  }
+  if (c < nf) s0 = __builtin_fma(c >= row ? Li[c] : 0.0, z[c], s0);
+  double sum = s0 + s1;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if (lane == 0) out[map ? map[row] : row] = sum;
 }
 
 // out = M v - sub  (row-major M n x n): one wavefront per row.
@@ -926,66 +1111,17 @@ inline int grid1(size_t n, int block = 256) {
 //     merge_factor_kernel copies the factored columns back, so every consumer finds L where it always was.
 constexpr int kPanelThreads = 320;     // four MFMA wavefronts + the inverse wavefront of the diagonal tile
 
-// chol_diag_kernel's algorithm on a tile staged in LDS (sB, row-major, stride kStageLd): L goes to Tout, the inverse to inv
-__device__ void chol_diag_tile(const double *sB, double (*sCol)[NB], double *sRinv, double *Tout, int ld, int k0, double *inv, int *fail) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < 4) {
-    double a[NB / 4];
-#pragma unroll
-    for (int m = 0; m < NB / 4; ++m) {
-      const int c = 4 * m + wave;
-      a[m] = (c <= lane) ? sB[lane * kStageLd + c] : 0.0;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int mo = j >> 2;
-      if (wave == (j & 3)) {
-        double d = readlane_f64(a[mo], j);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double rinv = rsqrt_refined(d);
-        const double l = (lane >= j) ? a[mo] * rinv : 0.0;
-        sCol[j & 1][lane] = l;
-        if (lane == j) sRinv[j & 1] = rinv;
-        if (lane >= j) Tout[(size_t)(k0 + lane) * ld + k0 + j] = l;
-      }
-      lds_barrier();
-      if (j + 1 < NB) {
-        const double lrow = sCol[j & 1][lane];
-#pragma unroll
-        for (int m = mo; m < NB / 4; ++m) a[m] = __builtin_fma(-lrow, sCol[j & 1][4 * m + wave], a[m]);
-      }
-    }
-    if (bad && lane == 0) atomicOr(fail, 1);
-  } else {
-    double a[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      lds_barrier();
-      const double xj = (((lane == j) ? 1.0 : 0.0) - a[j]) * sRinv[j & 1];
-      inv[j * NB + lane] = xj;
-      double col[NB];
-#pragma unroll
-      for (int k = j + 1; k < NB; ++k) col[k] = sCol[j & 1][k];
-#pragma unroll
-      for (int k = j + 1; k < NB; ++k) a[k] = __builtin_fma(col[k], xj, a[k]);
-    }
-  }
-}
-
 // grid (tc, tr) over the 64 x 64 tiles of the trailing trapezoid of panel k0 (as chol_update_kernel).
 // factor_next: the tile (k0 + 64, k0 + 64) is the next diagonal block to factor (k0 + 64 < nf).
 __global__ void __launch_bounds__(kPanelThreads) chol_panel_kernel(double *T, double *Tl, int ld, int nrows, int k0, const double *inv_k,
-                                                                   double *inv_next, int *fail, int factor_next) {
+                                                                   double *inv_next, int *fail, int factor_next, int ibase, int iend) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   double *sA = smem_d, *sBm = sA + NB * kStageLd, *sI = sBm + NB * kStageLd;
-  double (*sCol)[NB] = reinterpret_cast<double (*)[NB]>(sI + NB * kStageLd);
-  double *sRinv = &sCol[2][0];
+  double *sQ = sI + NB * kStageLd, *sRv = sQ + 32 * kTileQs;      // scratch of the diagonal tile (with sA and sI)
   const int r0 = k0 + NB + blockIdx.y * NB;
   const int c0 = k0 + NB + blockIdx.x * NB;
   if (c0 > r0 + NB - 1) return;  // tile entirely above the diagonal
+  if (r0 >= ibase && r0 < iend && r0 - ibase >= k0 + NB) return;      // identity rows that no panel has reached yet
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool mm = wave < 4;      // the MFMA wavefronts
   const int lr = (wave >> 1) * 32, lc = (wave & 1) * 32;
@@ -1065,7 +1201,7 @@ __global__ void __launch_bounds__(kPanelThreads) chol_panel_kernel(double *T, do
         }
   }
   __syncthreads();
-  chol_diag_tile(sBm, sCol, sRinv, Tl, ld, r0, inv_next, fail);
+  chol_diag_tile(sBm, kStageLd, sA, sI, sQ, sRv, Tl + (size_t)r0 * ld + r0, ld, inv_next, fail);
 }
 
 // the factored columns (and the solved rows below them) back from Tl into T
@@ -1084,23 +1220,43 @@ struct FactorWork {
 };
 thread_local FactorWork g_fwork;
 
+// the diagonal-tile kernel needs 110 KB of LDS: opt in once
+void launch_diag(hipStream_t s, const double *T, double *Tout, int ld, int k0, double *inv, int *fail) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsBytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(kDiagThreads), kDiagLdsBytes, s, T, Tout, ld, k0, inv, fail);
+}
+
 // Blocked Cholesky of the first nf (multiple of 64) columns of T; inv receives
 // the nf/64 inverted diagonal blocks (64x64 each).
-void factor_launches(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
+void factor_launches(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv, int ibase) {
+  const int iend = ibase >= 0 ? ibase + nf : -1;
+  if (ibase < 0) ibase = 1 << 30;
   for (int k0 = 0; k0 < nf; k0 += NB) {
     double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, T, ld, k0, inv_k, fail);
+    launch_diag(s, T, T, ld, k0, inv_k, fail);
     const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
-    if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, T, ld, nrows, k0, inv_k);
+    if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, T, ld, nrows, k0, inv_k, ibase, iend);
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
     if (tr > 0 && tc > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tc, tr), dim3(256), 0, s, T, ld, nrows, k0);
   }
 }
 
-void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv) {
+// ibase >= 0: rows [ibase, ibase + nf) of T hold an identity block (ibase a multiple of 64, at or below nf).  The panel
+// solves turn it into L^-T row by row -- row i is zero left of column i, so a 64-row block of it is skipped until the
+// panels reach its columns -- and a solve with the factor becomes ONE matrix-vector product with those rows
+// (inverse_rows_solve_kernel) instead of a block-by-block back substitution in a single workgroup, which one CU's
+// memory bandwidth bounds (the strips of L are n^2 / 2 doubles: 34 us at n = 512, 105 us at n = 1088).  The extra
+// tiles run on other CUs in the shadow of the diagonal tile's chain.
+void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, double *inv, int ibase = -1) {
   if (nf <= 0) return;
   static const bool fused = [] { const char *e = std::getenv("EGS_CHOL_FUSED"); return !(e && std::atoi(e) == 0); }();
-  if (!fused || nf <= NB) { factor_launches(s, T, ld, nrows, nf, fail, inv); return; }
+  if (!fused || nf <= NB) { factor_launches(s, T, ld, nrows, nf, fail, inv, ibase); return; }
+  const int iend = ibase >= 0 ? ibase + nf : -1;
+  if (ibase < 0) ibase = 1 << 30;
   const size_t need = (size_t)nrows * ld;
   if (g_fwork.cap < need) {
     if (g_fwork.p) { HIPCHK(hipStreamSynchronize(s)); (void)hipFree(g_fwork.p); g_fwork.p = nullptr; g_fwork.cap = 0; }
@@ -1108,24 +1264,24 @@ void factor(hipStream_t s, double *T, int ld, int nrows, int nf, int *fail, doub
     g_fwork.cap = need + need / 4;
   }
   double *Tl = g_fwork.p;
-  const size_t lds = (size_t)(3 * NB * kStageLd + 3 * NB) * sizeof(double);
+  const size_t lds = (size_t)(3 * NB * kStageLd + 32 * kTileQs + NB) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // the first diagonal block has no update before it
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(320), 0, s, T, Tl, ld, 0, inv, fail);
+  launch_diag(s, T, Tl, ld, 0, inv, fail);
   for (int k0 = 0; k0 < nf; k0 += NB) {
     double *inv_k = inv + (size_t)(k0 / NB) * NB * NB;
     const int tr = (nrows - (k0 + NB) + NB - 1) / NB, tc = (ld - (k0 + NB) + NB - 1) / NB;
     if (tr > 0 && tc > 0) {
       const int factor_next = (k0 + NB < nf) ? 1 : 0;
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(tc, tr), dim3(kPanelThreads), lds, s, T, Tl, ld, nrows, k0, inv_k, inv_k + NB * NB, fail, factor_next);
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(tc, tr), dim3(kPanelThreads), lds, s, T, Tl, ld, nrows, k0, inv_k, inv_k + NB * NB, fail, factor_next, ibase, iend);
     } else {
       // nothing to the right of this panel: only the rows below it are left to solve (k0 + 64 == nf here)
       const int slabs = (nrows - (k0 + NB) + NB - 1) / NB;
-      if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, Tl, ld, nrows, k0, inv_k);
+      if (slabs > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(slabs), dim3(256), 0, s, T, Tl, ld, nrows, k0, inv_k, ibase, iend);
     }
   }
   hipLaunchKernelGGL(merge_factor_kernel, dim3(grid1((size_t)nrows * nf)), dim3(256), 0, s, T, Tl, ld, nrows, nf);
@@ -1195,7 +1351,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     return res.solved != 0;
   }
   const int npad_max = (n + NB - 1) / NB * NB;
-  Buf<double> T((size_t)(npad_max + 1) * npad_max), lohi_d(2 * (size_t)n), Cb(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
+  Buf<double> T((size_t)(2 * npad_max + 1) * npad_max), lohi_d(2 * (size_t)n), Cb(n), beff(n), r(n), bx(n), bw(n), xs(npad_max), dinv((size_t)npad_max * NB);
   Buf<uint8_t> S_d(n);
   Buf<int> idx_d(n), fail_d(1);
   Buf<MurtyState> st_d(1);
@@ -1243,11 +1399,11 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     const int nspad = (ns + NB - 1) / NB * NB;
     hipLaunchKernelGGL(murty_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, db, S_d.p, Cb.p, box_fix ? 1 : 0, beff.p, dx);
     if (ns > 0) {
-      hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
-                         nspad, beff.p, T.p);
-      factor(s, T.p, nspad, nspad + 1, nspad, fail_d.p, dinv.p);
-      hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, nspad, nspad, nspad, ns, idx_d.p, dx, xs.p,
-                         dinv.p);
+      hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(2 * nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
+                         nspad, beff.p, T.p, 1);
+      factor(s, T.p, nspad, 2 * nspad + 1, nspad, fail_d.p, dinv.p, nspad);
+      hipLaunchKernelGGL(inverse_rows_solve_kernel, dim3((ns + 3) / 4), dim3(256), 0, s, T.p, nspad, nspad, nspad, 2 * nspad, ns,
+                         idx_d.p, dx);
     }
     // r = A x - b; w(!S) = r.  (The reference, lcp.cc:219-221, uses x(S) only: x(!S) = lo = 0 there, so A x(S) == A x.)
     hipLaunchKernelGGL(murty_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, S_d.p, r.p, dw);
@@ -1255,7 +1411,8 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     advance(flip_mode, 1e-9, 1);     // lcp.cc:125-137: the best iterate by "goodness" is kept by the kernel
     if (trace) {
       const auto t_now = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d, %.3f ms\n", pivots, ns, n, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d, %.3f ms; then %d infeasible, %d flipped\n", pivots, ns, n,
+                   std::chrono::duration<double, std::milli>(t_now - t_prev).count(), rec->ninf, rec->flipped);
       t_prev = t_now;
     }
     ++iter;
@@ -1443,7 +1600,7 @@ double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *sp
   HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(zero.p, 0, N * sizeof(double), s));
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
-  hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p);
+  hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p, 0);
   factor(s, T.p, npad, npad + 1, npad, fail_d.p, dinv.p);
   hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, s, T.p, npad, N, mm.p);
   double h[4] = {1, 1, 0, 0};
@@ -1526,7 +1683,7 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
   HIPCHK(hipMemsetAsync(xw.p, 0, (size_t)2 * N * sizeof(double), s));     // w = 0 on the equality rows, lcp.cc:332-333
   if (ne) {
     hipLaunchKernelGGL(xe_rhs_kernel, dim3(nepad / NB), dim3(1024), 0, s, T.p, nepad, ni, xi.p);
-    hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p,
+    launch_back_solve(s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p,
                        dinv.p);
     hipLaunchKernelGGL(scatter_kernel, dim3(grid1(ne)), dim3(256), 0, s, ne, dE_p, xe.p, xw.p);
   }
@@ -1654,7 +1811,7 @@ bool box_lcp_schur(hipStream_t s, int n, double *A, const double *b_arg, const d
   // y = Z^-1 (c - B' z) = L^-T (L^-1 c - Q z)
   std::vector<double> xih(ni), wih(ni), xeh(ne);
   hipLaunchKernelGGL(xe_rhs_kernel, dim3(nepad / NB), dim3(1024), 0, s, T.p, nepad, ni, xi.p);
-  hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p, dinv.p);
+  launch_back_solve(s, T.p, ld, nepad, nepad + ni, ne, (const int *)nullptr, xe.p, xs.p, dinv.p);
   HIPCHK(hipMemcpyAsync(xeh.data(), xe.p, ne * sizeof(double), hipMemcpyDeviceToHost, s));
   if (ni) {
     HIPCHK(hipMemcpyAsync(xih.data(), xi.p, ni * sizeof(double), hipMemcpyDeviceToHost, s));
