@@ -558,8 +558,12 @@ __global__ void extract_schur_kernel(const double *T, int nepad, int ni, double 
 // Pivot trapezoid: A(S,S) padded with an identity block; then nspad identity rows (they become L^-T, see factor());
 // b_eff(S) as last row.
 __global__ void build_pivot_kernel(const double *lhs, int n, const int *S, int ns, int nspad, const double *beff,
-                                   double *T, int identity_rows) {
+                                   double *T, int identity_rows, int *pos0, int *idx0) {
   const int ld = nspad, ib = identity_rows ? nspad : 0, rows = nspad + ib + 1;
+  if (pos0) {      // this set becomes the base of the bordered pivots (murty_advance_kernel validates pos0 through idx0)
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (size_t)ns) { pos0[S[k]] = (int)k; idx0[k] = S[k]; }
+  }
   const size_t total = (size_t)rows * ld;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / ld), c = (int)(idx % ld);
@@ -573,12 +577,14 @@ __global__ void build_pivot_kernel(const double *lhs, int n, const int *S, int n
 }
 
 // x = L^-T z from the rows the factorisation turned into L^-T (factor(), ibase): x_i = sum_{c >= i} Linvt[i][c] z[c],
-// z = T[zrow][.] = L^-1 b.  One wavefront per row; x goes to out[map ? map[i] : i] for i < nreal.
-__global__ void __launch_bounds__(256) inverse_rows_solve_kernel(const double *T, int ld, int nf, int ibase, int zrow, int nreal,
-                                                                 const int *map, double *out) {
+// z = L^-1 b.  One wavefront per row; x goes to out[map ? map[i] : i] for i < nreal.
+// keep: rows whose map[row] has keep == 0 are not written (indexes that left the set since the factorisation).
+__global__ void __launch_bounds__(256) inverse_rows_solve_kernel(const double *T, int ld, int nf, int ibase, const double *z, int nreal,
+                                                                 const int *map, double *out, const uint8_t *keep) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nreal) return;
-  const double *Li = T + (size_t)(ibase + row) * ld, *z = T + (size_t)zrow * ld;
+  if (keep && !keep[map[row]]) return;
+  const double *Li = T + (size_t)(ibase + row) * ld;
   double s0 = 0.0, s1 = 0.0;
   int c = (row & ~63) + lane;      // whole 64-column groups from the one that holds the diagonal
   for (; c + 64 < nf; c += 128) {
@@ -709,7 +715,9 @@ struct MurtyStep {        // one per pivot, read by the host after the synchroni
   int ns;                 // |S| after the flips: the size of the next pivot's system
   int ninf;               // number of infeasible indexes before the flips
   int flipped;
-  int pad;
+  int nd, nr;             // |S \ S0| and |S0 \ S| against the factored base set S0 (-1: not tracked)
+  int seq;                // the launch's sequence number, stored last (system scope): the host polls it instead of
+                          // waiting for the stream (a completion signal costs ~15 us of host latency per pivot)
 };
 struct MurtyState {       // block-rule and best-iterate memory, device resident
   int best_ninf, patience;
@@ -762,7 +770,8 @@ __global__ void __launch_bounds__(256) murty_resid_kernel(const double *M, int n
 __global__ void __launch_bounds__(1024) murty_advance_kernel(int n, const double *x, const double *w, const double *r, uint8_t *S,
                                                              double *Cb, const double *lo, const double *hi, int mode, double tol,
                                                              int keep_best, MurtyState *st, double *bx, double *bw, int *idx,
-                                                             const int *fail_a, const int *fail_b, MurtyStep *out) {
+                                                             const int *fail_a, const int *fail_b, MurtyStep *out,
+                                                             const int *pos0, const int *idx0, int n0, int *Dl, int *Rl, int list_cap, int seq) {
   __shared__ int s_first, s_last, s_ninf, s_oob, s_wbad, s_improved, s_all, s_flip, s_flipped;
   __shared__ double s_res[1024], s_good[1024];
   __shared__ int s_scan[1024];
@@ -835,13 +844,202 @@ __global__ void __launch_bounds__(1024) murty_advance_kernel(int n, const double
   }
   int pos = s_scan[tid] - cnt;
   for (int i = i0; i < i1; ++i) if (S[i]) idx[pos++] = i;
+  const int ns_total = s_scan[1023];
+  // the difference against the factored base set S0 = idx0[0 .. n0): D = S \ S0, R = S0 \ S, ascending (n < 32768).
+  // pos0 is never cleared: an entry counts only if idx0 points back at it.
+  auto in_base = [&](int i) { const int q = pos0[i]; return q >= 0 && q < n0 && idx0[q] == i; };
+  int nd_total = -1, nr_total = -1;
+  if (pos0) {
+    int cd = 0, cr = 0;
+    for (int i = i0; i < i1; ++i) { const bool in0 = in_base(i); cd += (S[i] && !in0) ? 1 : 0; cr += (!S[i] && in0) ? 1 : 0; }
+    __syncthreads();
+    s_scan[tid] = cd | (cr << 16);
+    __syncthreads();
+    for (int k = 1; k < 1024; k <<= 1) {
+      const int v = tid >= k ? s_scan[tid - k] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    nd_total = s_scan[1023] & 0xffff; nr_total = s_scan[1023] >> 16;
+    if (nd_total + nr_total <= list_cap) {
+      int pd = (s_scan[tid] & 0xffff) - cd, pr = (s_scan[tid] >> 16) - cr;
+      for (int i = i0; i < i1; ++i) {
+        const bool in0 = in_base(i);
+        if (S[i] && !in0) Dl[pd++] = i;
+        if (!S[i] && in0) Rl[pr++] = i;
+      }
+    }
+  }
   if (tid == 0) {
     out->first_offender = s_first; out->out_of_bounds = s_oob; out->w_bad = s_wbad;
     out->fail = (fail_a ? *fail_a : 0) | (fail_b ? *fail_b : 0);
     out->resid2 = s_res[0]; out->goodness = s_good[0];
-    out->ns = s_scan[1023]; out->ninf = s_ninf; out->flipped = s_flipped; out->pad = 0;
+    out->ns = ns_total; out->ninf = s_ninf; out->flipped = s_flipped; out->nd = nd_total; out->nr = nr_total;
+    __threadfence_system();
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// ---- pivots that differ little from a factored one ---------------------------------------------------------
+// Block pivoting ends with a few small corrections of S (the N = 2048 problem: 486, 440, 226, 121, 40, 11, 2 flips), the
+// reference's single-index rule changes one index per pivot -- and a fresh factorisation costs the same 64-column
+// latency chain every time.  With S0 the set of the last factorisation (L and W = L^-T in T, see factor()), D = S \ S0
+// and R = S0 \ S, m = |D| + |R| <= 64, the new x solves the bordered system
+//     [A00  A0D  E_R] [x0]   [b0]
+//     [AD0  ADD   0 ] [xD] = [bD]          (the multipliers mu pin x_R = 0)
+//     [E_R'  0    0 ] [mu]   [0 ]
+// by block elimination on the old factor:  Y = L^-1 [A0D E_R],  z0 = L^-1 b0,  C = [ADD 0; 0 0] - Y'Y (quasi-definite:
+// no pivoting needed),  C zz = [bD; 0] - Y'z0,  x0 = W (z0 - Y zz): two products with W (parallel over all CUs), one
+// m x m elimination in one workgroup -- no panel chain.
+constexpr int kBorderMax = 64;            // m
+constexpr int kBorderStride = 68;         // row stride of U and Y: m + 1 columns (the last is b0 / z0), padded
+
+// U (n0pad x kBorderStride): columns A(S0, D), E_R, b0; rows beyond n0 zero
+__global__ void border_build_kernel(const double *A, int n, const double *beff, const int *idx0, int n0, int n0pad, const int *pos0,
+                                    const int *Dl, int nd, const int *Rl, int nr, double *U) {
+  const int m = nd + nr;
+  const size_t total = (size_t)n0pad * kBorderStride;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / kBorderStride), j = (int)(e % kBorderStride);
+    double v = 0.0;
+    if (k < n0) {
+      if (j < nd) v = A[(size_t)idx0[k] * n + Dl[j]];
+      else if (j < m) v = (pos0[Rl[j - nd]] == k) ? 1.0 : 0.0;
+      else if (j == m) v = beff[idx0[k]];
+    }
+    U[e] = v;
+  }
+}
+
+// Y = L^-1 U = W'U (W[k][c] = T[ibase + k][c], zero for k > c) in 64 x 64 tiles of W: workgroup (tile (cb, kb <= cb), column
+// quarter jq) forms Yp[kb][cb 64 + c][j] = sum over the tile's k of W[k][c] U[k][j] for 17 columns j.  Both operands are
+// read along k-major rows and staged in LDS; lane = c, wavefront w takes the columns jq 17 + w, + 4, ... (its U reads are
+// wavefront-uniform broadcasts).
+constexpr int kBorderJ = kBorderStride / 4;      // 17 columns per quarter
+__global__ void __launch_bounds__(256) border_forward_kernel(const double *T, int ld, int ibase, int n0, const double *U, double *Yp,
+                                                             int n0pad) {
+  __shared__ double sW[NB][NB + 1], sU[NB][kBorderJ + 1];
+  int cbi = 0, t = blockIdx.x;      // tile index -> (cb, kb), kb <= cb
+  while (t > cbi) { t -= cbi + 1; ++cbi; }
+  const int kbi = t, cb = cbi * NB, kb = kbi * NB, j0 = blockIdx.y * kBorderJ;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int k = e >> 6, c = e & 63;
+    sW[k][c] = (kb + k < n0 && kb + k <= cb + c) ? T[(size_t)(ibase + kb + k) * ld + cb + c] : 0.0;
+  }
+  for (int e = threadIdx.x; e < NB * kBorderJ; e += 256) {
+    const int k = e / kBorderJ, j = e % kBorderJ;
+    sU[k][j] = U[(size_t)(kb + k) * kBorderStride + j0 + j];
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NJ = (kBorderJ + 3) / 4;      // 5 columns per wavefront (the last wavefronts have 4)
+  double acc[NJ];
+#pragma unroll
+  for (int b = 0; b < NJ; ++b) acc[b] = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < NB; ++k) {
+    const double wv = sW[k][c];
+#pragma unroll
+    for (int b = 0; b < NJ; ++b) if (w + 4 * b < kBorderJ) acc[b] = __builtin_fma(wv, sU[k][w + 4 * b], acc[b]);
+  }
+  double *out = Yp + ((size_t)kbi * n0pad + cb + c) * kBorderStride + j0;
+#pragma unroll
+  for (int b = 0; b < NJ; ++b) if (w + 4 * b < kBorderJ) out[w + 4 * b] = acc[b];
+}
+
+// Y = the sum of its tiles' shares for one 64-row block per workgroup, and the block's share of Y'Y (all m + 1 columns:
+// the last row is Y'z0), lower triangle.
+__global__ void __launch_bounds__(256) border_gram_kernel(const double *Yp, int n0pad, int n0, int m1, double *Y, double *Cpart) {
+  __shared__ double sY[NB][kBorderStride + 1];
+  const int cbi = blockIdx.x, cb = cbi * NB;
+  {
+    // the block's NB x kBorderStride entries are contiguous in every partial copy: element e of thread t is t + 256 i
+    constexpr int PER = NB * kBorderStride / 256;      // 17
+    double v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = 0.0;
+    for (int kbi = 0; kbi <= cbi; ++kbi) {
+      const double *src = Yp + ((size_t)kbi * n0pad + cb) * kBorderStride;
+      double ld_[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) ld_[i] = src[threadIdx.x + 256 * i];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v[i] += ld_[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + 256 * i, c = e / kBorderStride, j = e % kBorderStride;
+      const double val = (cb + c < n0 && j < m1) ? v[i] : 0.0;
+      Y[(size_t)(cb + c) * kBorderStride + j] = val;
+      sY[c][j] = val;
+    }
+  }
+  __syncthreads();
+  double *Cp = Cpart + (size_t)cbi * kBorderStride * kBorderStride;
+  for (int e = threadIdx.x; e < m1 * m1; e += 256) {
+    const int j1 = e / m1, j2 = e % m1;
+    double sacc = 0.0;
+    if (j2 <= j1) {
+#pragma unroll 16
+      for (int r = 0; r < NB; ++r) sacc = __builtin_fma(sY[r][j1], sY[r][j2], sacc);
+    }
+    Cp[j1 * kBorderStride + j2] = sacc;
+  }
+}
+
+// C zz = g in one workgroup: C = [A(D,D) 0; 0 0] - sum of the blocks' Y'Y, g = [b(D); 0] - Y'z0; symmetric elimination
+// without pivoting (C is quasi-definite: the D block positive, the R block negative definite).
+__global__ void __launch_bounds__(256) border_small_kernel(const double *Cpart, int nblocks, const double *A, int n, const double *beff,
+                                                           const int *Dl, int nd, int m, double *zz, int *fail) {
+  __shared__ double M[kBorderMax][kBorderMax + 2];      // augmented with g
+  const int tid = threadIdx.x, m1 = m + 1;
+  for (int e = tid; e < m * m1; e += 256) {
+    const int j1 = e / m1, j2 = e % m1;
+    const int hi = j2 == m ? m : (j1 > j2 ? j1 : j2), lo = j2 == m ? j1 : (j1 > j2 ? j2 : j1);      // Cpart holds the lower triangle
+    const double *src = Cpart + hi * kBorderStride + lo;
+    double sum = 0.0;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+      const double a0 = src[(size_t)b * kBorderStride * kBorderStride], a1 = src[(size_t)(b + 1) * kBorderStride * kBorderStride],
+                   a2 = src[(size_t)(b + 2) * kBorderStride * kBorderStride], a3 = src[(size_t)(b + 3) * kBorderStride * kBorderStride];
+      sum += a0; sum += a1; sum += a2; sum += a3;
+    }
+    for (; b < nblocks; ++b) sum += src[(size_t)b * kBorderStride * kBorderStride];
+    double c0 = 0.0;
+    if (j2 == m) c0 = j1 < nd ? beff[Dl[j1]] : 0.0;
+    else if (j1 < nd && j2 < nd) c0 = A[(size_t)Dl[j1] * n + Dl[j2]];
+    M[j1][j2] = c0 - sum;
+  }
+  __syncthreads();
+  // Gauss-Jordan: step k clears column k in every other row, so the solution is M[i][m] / M[i][i] at the end.  Row k and
+  // column k are only read in step k and every other entry has one writer: in place, one barrier per step.  Thread
+  // (i = tid / 4, q = tid % 4) owns the columns j = q, q + 4, ... of row i.
+  const int i = tid >> 2, q = tid & 3;
+  for (int k = 0; k < m; ++k) {
+    const double piv = M[k][k];
+    if (tid == 0 && !(fabs(piv) > 0.0)) atomicOr(fail, 1);
+    if (i < m && i != k) {
+      const double f = -M[i][k] / piv;
+      for (int j = k + 1 + ((q - (k + 1)) & 3); j < m1; j += 4) M[i][j] = __builtin_fma(f, M[k][j], M[i][j]);
+    }
+    __syncthreads();
+  }
+  if (tid < m) zz[tid] = M[tid][m] / M[tid][tid];
+}
+
+// v = z0 - Y zz (the right-hand side of the product with W), one wavefront per row, and x_D = zz[0 .. nd) into x
+__global__ void __launch_bounds__(256) border_v_kernel(const double *Y, int n0pad, int m, const double *zz, double *v, const int *Dl, int nd, double *x) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x < nd) x[Dl[threadIdx.x]] = zz[threadIdx.x];      // nd <= kBorderMax <= 256
+  if (row >= n0pad) return;
+  const double *y = Y + (size_t)row * kBorderStride;
+  double sum = lane < m ? -y[lane] * zz[lane] : 0.0;      // m <= 64
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if (lane == 0) v[row] = y[m] + sum;
+}
+
+
 
 // ---- small problems: the whole pivot loop in ONE workgroup ----------------------
 // The reference's own ensembles give the dense solver a few dozen rows (Cairn(4): 3 rows per
@@ -1303,7 +1501,10 @@ MurtyStep *pinned_step() {
     ~Holder() { if (p) (void)hipHostFree(p); }
   };
   thread_local Holder h;
-  if (!h.p) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h.p), sizeof(MurtyStep), hipHostMallocDefault));
+  if (!h.p) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h.p), sizeof(MurtyStep), hipHostMallocDefault));
+    std::memset(h.p, 0, sizeof(MurtyStep));
+  }
   return h.p;
 }
 
@@ -1355,8 +1556,18 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   Buf<uint8_t> S_d(n);
   Buf<int> idx_d(n), fail_d(1);
   Buf<MurtyState> st_d(1);
+  // bordered pivots (see border_* kernels): the base set of the last factorisation and the work arrays
+  static const bool border_on = [] { const char *e = std::getenv("EGS_DENSE_BORDER"); return !(e && std::atoi(e) == 0); }();
+  const bool track_base = border_on && n <= 2048;      // (the forward product keeps n / 64 partial copies of Y)
+  Buf<int> pos0(track_base ? n : 0), idx0(track_base ? npad_max : 0), Dl(track_base ? kBorderMax : 0), Rl(track_base ? kBorderMax : 0);
+  Buf<double> Um(track_base ? (size_t)npad_max * kBorderStride : 0), Ym(track_base ? (size_t)npad_max * kBorderStride : 0),
+      Cpart(track_base ? (size_t)(npad_max / NB) * kBorderStride * kBorderStride : 0), zz(track_base ? kBorderStride : 0), vv(track_base ? npad_max : 0),
+      Yp(track_base ? (size_t)(npad_max / NB) * npad_max * kBorderStride : 0);
+  int base_n0 = -1;      // |S0|, or -1 while nothing is factored
+  if (track_base) HIPCHK(hipMemsetAsync(pos0.p, 0xff, (size_t)n * sizeof(int), s));
   const double *lo_d = lohi_d.p, *hi_d = lohi_d.p + n;
   MurtyStep *rec = pinned_step();
+  int seq = rec->seq;      // continues across calls (the record is per host thread)
   {
     std::vector<double> lohi(2 * (size_t)n);
     std::copy(lo.begin(), lo.end(), lohi.begin());
@@ -1370,14 +1581,24 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   // check the iterate on the device, flip for the next pivot there too, and read the 64-byte record
   auto advance = [&](int mode, double tol, int keep_best) {
     hipLaunchKernelGGL(murty_advance_kernel, dim3(1), dim3(1024), 0, s, n, dx, dw, r.p, S_d.p, Cb.p, lo_d, hi_d, mode, tol, keep_best,
-                       st_d.p, bx.p, bw.p, idx_d.p, fail_d.p, extra_fail, rec);
+                       st_d.p, bx.p, bw.p, idx_d.p, fail_d.p, extra_fail, rec, track_base ? pos0.p : (const int *)nullptr, idx0.p, base_n0 > 0 ? base_n0 : 0,
+                       Dl.p, Rl.p, kBorderMax, ++seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
+    // the record is in host-coherent memory and its sequence number is written last: poll it (every later launch is
+    // ordered by the stream anyway); fall back to the stream's own completion if it does not show up
+    const auto t_poll = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; __atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
+      if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() > 0.05) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) != seq) throw std::runtime_error("dense LCP: the pivot record did not arrive");
+        break;
+      }
+    }
   };
   auto is_solution = [&](double tol) {
     return rec->first_offender == 0x7fffffff && !rec->out_of_bounds && !rec->w_bad && std::sqrt(rec->resid2) <= tol;
   };
-  int iter = 0, pivots = 0;
+  int iter = 0, pivots = 0, bordered = 0;
   bool force = box_fix, solved = false, timed_out = false;
   // the start iterate: its goodness opens the best-solution memory; a box problem solves once before the first flip,
   // the reference's loop (lcp.cc:196-198) checks and flips first
@@ -1398,12 +1619,26 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     const int ns = rec->ns;
     const int nspad = (ns + NB - 1) / NB * NB;
     hipLaunchKernelGGL(murty_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, db, S_d.p, Cb.p, box_fix ? 1 : 0, beff.p, dx);
-    if (ns > 0) {
+    const int nd = rec->nd, nr = rec->nr, mb = nd + nr;
+    if (track_base && base_n0 > 0 && nd >= 0 && mb <= kBorderMax && ns > 0) {
+      // a few indexes away from the factored set: the bordered system on the old factor
+      const int n0 = base_n0, n0pad = (n0 + NB - 1) / NB * NB, nblocks = n0pad / NB;
+      hipLaunchKernelGGL(border_build_kernel, dim3(grid1((size_t)n0pad * kBorderStride)), dim3(256), 0, s, dA, n, beff.p, idx0.p, n0, n0pad,
+                         pos0.p, Dl.p, nd, Rl.p, nr, Um.p);
+      hipLaunchKernelGGL(border_forward_kernel, dim3(nblocks * (nblocks + 1) / 2, 4), dim3(256), 0, s, T.p, n0pad, n0pad, n0, Um.p, Yp.p, n0pad);
+      hipLaunchKernelGGL(border_gram_kernel, dim3(nblocks), dim3(256), 0, s, Yp.p, n0pad, n0, mb + 1, Ym.p, Cpart.p);
+      if (mb > 0)
+        hipLaunchKernelGGL(border_small_kernel, dim3(1), dim3(256), 0, s, Cpart.p, nblocks, dA, n, beff.p, Dl.p, nd, mb, zz.p, fail_d.p);
+      hipLaunchKernelGGL(border_v_kernel, dim3(n0pad / 4), dim3(256), 0, s, Ym.p, n0pad, mb, zz.p, vv.p, Dl.p, nd, dx);
+      hipLaunchKernelGGL(inverse_rows_solve_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, T.p, n0pad, n0pad, n0pad, vv.p, n0, idx0.p, dx, S_d.p);
+      ++bordered;
+    } else if (ns > 0) {
       hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(2 * nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
-                         nspad, beff.p, T.p, 1);
+                         nspad, beff.p, T.p, 1, track_base ? pos0.p : (int *)nullptr, idx0.p);
       factor(s, T.p, nspad, 2 * nspad + 1, nspad, fail_d.p, dinv.p, nspad);
-      hipLaunchKernelGGL(inverse_rows_solve_kernel, dim3((ns + 3) / 4), dim3(256), 0, s, T.p, nspad, nspad, nspad, 2 * nspad, ns,
-                         idx_d.p, dx);
+      hipLaunchKernelGGL(inverse_rows_solve_kernel, dim3((ns + 3) / 4), dim3(256), 0, s, T.p, nspad, nspad, nspad,
+                         T.p + (size_t)2 * nspad * nspad, ns, idx_d.p, dx, (const uint8_t *)nullptr);
+      if (track_base) base_n0 = ns;      // (build_pivot_kernel recorded the set: the base of the bordered pivots that may follow)
     }
     // r = A x - b; w(!S) = r.  (The reference, lcp.cc:219-221, uses x(S) only: x(!S) = lo = 0 there, so A x(S) == A x.)
     hipLaunchKernelGGL(murty_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, S_d.p, r.p, dw);
@@ -1411,13 +1646,15 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     advance(flip_mode, 1e-9, 1);     // lcp.cc:125-137: the best iterate by "goodness" is kept by the kernel
     if (trace) {
       const auto t_now = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d, %.3f ms; then %d infeasible, %d flipped\n", pivots, ns, n,
+      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d (%s, +%d -%d against the factored set), %.3f ms; then %d infeasible, %d flipped\n",
+                   pivots, ns, n, (track_base && base_n0 > 0 && nd >= 0 && mb <= kBorderMax && ns > 0) ? "bordered" : "factored", nd, nr,
                    std::chrono::duration<double, std::milli>(t_now - t_prev).count(), rec->ninf, rec->flipped);
       t_prev = t_now;
     }
     ++iter;
   }
   if (!solved && iter < max_iterations && !timed_out && !rec->fail) solved = is_solution(1e-9);
+  if (trace) std::fprintf(stderr, "dense trace: %d pivots, %d of them bordered\n", pivots, bordered);
   *pivots_out = pivots;
   if (rec->fail) { if (msg) *msg = "a principal submatrix A(S,S) is not positive definite"; return false; }
   if (solved) return true;  // x, w hold the solution iterate (== best, see lcp.cc:241)
@@ -1600,7 +1837,7 @@ double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *sp
   HIPCHK(hipMemcpyAsync(idx_d.p, idx.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(zero.p, 0, N * sizeof(double), s));
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
-  hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p, 0);
+  hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(npad + 1) * npad)), dim3(256), 0, s, dA, N, idx_d.p, N, npad, zero.p, T.p, 0, (int *)nullptr, (int *)nullptr);
   factor(s, T.p, npad, npad + 1, npad, fail_d.p, dinv.p);
   hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, s, T.p, npad, N, mm.p);
   double h[4] = {1, 1, 0, 0};
