@@ -1508,6 +1508,26 @@ MurtyStep *pinned_step() {
   return h.p;
 }
 
+// a second stream (and an event) per host thread for work that overlaps the main stream's
+hipStream_t side_stream() {
+  struct Holder {
+    hipStream_t q = nullptr;
+    ~Holder() { if (q) (void)hipStreamDestroy(q); }
+  };
+  thread_local Holder h;
+  if (!h.q) HIPCHK(hipStreamCreateWithFlags(&h.q, hipStreamNonBlocking));
+  return h.q;
+}
+hipEvent_t side_event() {
+  struct Holder {
+    hipEvent_t e = nullptr;
+    ~Holder() { if (e) (void)hipEventDestroy(e); }
+  };
+  thread_local Holder h;
+  if (!h.e) HIPCHK(hipEventCreateWithFlags(&h.e, hipEventDisableTiming));
+  return h.e;
+}
+
 struct HostWords { unsigned long long sym[2]; int fail; int pad; };   // pinned landing area of the deferred checks
 HostWords *pinned_words() {
   struct Holder {
@@ -1672,6 +1692,15 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
 
 }  // namespace
 
+namespace {
+// The host entry uploads the lower block trapezoids of A first and hands the rest over as `upload_rest`: the Schur stage
+// (which reads the lower triangle only) is enqueued before the host pushes the remainder on a second stream, where the
+// symmetry check then runs; `side` is that stream.
+bool dense_mixed_impl(hipStream_t s, int N, const double *dA_in, const double *db_in, const uint8_t *C, const double *lo, const double *hi,
+                      bool use_bounds, bool block_pivoting, int max_pivots, double max_seconds, double *x, double *w, double *dx_out,
+                      int *pivots, std::string *msg, const std::function<void()> *upload_rest, hipStream_t side);
+}  // namespace
+
 bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double *b, const uint8_t *C, const double *lo,
                              const double *hi, bool use_bounds, bool block_pivoting, double *x, double *w, int *pivots,
                              std::string *msg, int max_pivots, double max_seconds) {
@@ -1681,8 +1710,32 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   const auto t_a = std::chrono::steady_clock::now();
   Buf<double> dA((size_t)N * N), db(N);
   const auto t_b = std::chrono::steady_clock::now();
-  // (a pageable source: ROCm 7.2 moves these 33.6 MB in 0.6 ms on MI355X's host; a hand-made threaded staging copy took 0.9)
-  HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+  // (a pageable source: ROCm 7.2 moves these 33.6 MB in 0.6 ms on MI355X's host; a hand-made threaded staging copy took 0.9).
+  // From N = 1024 on the lower block trapezoids go first (62 % of the bytes with four blocks of rows, 0.41 ms) -- all the
+  // Schur stage reads -- and the rest follows on a second stream while the device factors.
+  const int chunk = N >= 1024 ? ((N / 4 + 63) / 64) * 64 : 0;
+  hipStream_t side = nullptr;
+  std::function<void()> rest;
+  if (chunk) {
+    side = side_stream();
+    for (int r0 = 0; r0 < N; r0 += chunk) {
+      const int r1 = std::min(N, r0 + chunk);
+      HIPCHK(hipMemcpy2DAsync(dA.p + (size_t)r0 * N, (size_t)N * sizeof(double), A + (size_t)r0 * N, (size_t)N * sizeof(double),
+                              (size_t)r1 * sizeof(double), (size_t)(r1 - r0), hipMemcpyHostToDevice, s));
+    }
+    hipEvent_t ev = side_event();
+    HIPCHK(hipEventRecord(ev, s));
+    HIPCHK(hipStreamWaitEvent(side, ev, 0));      // (the symmetry check on the side stream reads the lower part too)
+    rest = [&, chunk, side]() {
+      for (int r0 = 0; r0 + chunk < N; r0 += chunk) {
+        const int r1 = r0 + chunk;
+        HIPCHK(hipMemcpy2DAsync(dA.p + (size_t)r0 * N + r1, (size_t)N * sizeof(double), A + (size_t)r0 * N + r1, (size_t)N * sizeof(double),
+                                (size_t)(N - r1) * sizeof(double), (size_t)chunk, hipMemcpyHostToDevice, side));
+      }
+    };
+  } else {
+    HIPCHK(hipMemcpyAsync(dA.p, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+  }
   if (trace) {
     HIPCHK(hipStreamSynchronize(s));
     const auto t_c = std::chrono::steady_clock::now();
@@ -1690,8 +1743,8 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
                  std::chrono::duration<double, std::milli>(t_c - t_b).count());
   }
   HIPCHK(hipMemcpyAsync(db.p, b, N * sizeof(double), hipMemcpyHostToDevice, s));
-  return dense_mixed_constraints_device(s, N, dA.p, db.p, C, lo, hi, use_bounds, block_pivoting, max_pivots, max_seconds, x, w,
-                                        nullptr, pivots, msg);
+  return dense_mixed_impl(s, N, dA.p, db.p, C, lo, hi, use_bounds, block_pivoting, max_pivots, max_seconds, x, w, nullptr, pivots, msg,
+                          chunk ? &rest : nullptr, side);
 }
 
 __global__ void scatter_kernel(int n, const int *idx, const double *src, double *dst) {
@@ -1860,6 +1913,14 @@ double dense_condition_estimate(hipStream_t s, int N, const double *dA, bool *sp
 bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, const double *db_in, const uint8_t *C,
                                     const double *lo, const double *hi, bool use_bounds, bool block_pivoting, int max_pivots,
                                     double max_seconds, double *x, double *w, double *dx_out, int *pivots, std::string *msg) {
+  return dense_mixed_impl(s, N, dA_in, db_in, C, lo, hi, use_bounds, block_pivoting, max_pivots, max_seconds, x, w, dx_out, pivots, msg,
+                          nullptr, nullptr);
+}
+
+namespace {
+bool dense_mixed_impl(hipStream_t s, int N, const double *dA_in, const double *db_in, const uint8_t *C, const double *lo, const double *hi,
+                      bool use_bounds, bool block_pivoting, int max_pivots, double max_seconds, double *x, double *w, double *dx_out,
+                      int *pivots, std::string *msg, const std::function<void()> *upload_rest, hipStream_t side) {
   if (pivots) *pivots = 0;
   if (N == 0) return true;
   const auto t_dev0 = std::chrono::steady_clock::now();
@@ -1882,16 +1943,25 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
   // failure flag) is read at the first synchronisation the pivot loop makes anyway, not at one of its own.
   Buf<unsigned long long> sym_d(2);
   HostWords *host = pinned_words();
-  HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(symmetry_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, s, dA.p, N, sym_d.p);
-  HIPCHK(hipMemcpyAsync(host->sym, sym_d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  auto check_symmetry = [&](hipStream_t q) {
+    HIPCHK(hipMemsetAsync(sym_d.p, 0, 2 * sizeof(unsigned long long), q));
+    hipLaunchKernelGGL(symmetry_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, q, dA.p, N, sym_d.p);
+    HIPCHK(hipMemcpyAsync(host->sym, sym_d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, q));
+  };
+  if (!upload_rest) check_symmetry(s);
   // Schur stage: factor the E columns of [A_ee A_ei; A_ie A_ii; b^T]   (lcp.cc:286-294)
-  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE_p, ne, nepad, dI_p, ni, T.p, 0);
+  hipLaunchKernelGGL(build_schur_kernel, dim3(grid1((size_t)rows * ld)), dim3(256), 0, s, dA.p, db.p, N, dE_p, ne, nepad, dI_p, ni, T.p,
+                     upload_rest ? 1 : 0);
   factor(s, T.p, ld, rows, nepad, fail_d.p, dinv.p);
   if (ni) hipLaunchKernelGGL(extract_schur_kernel, dim3(grid1((size_t)ni * ni)), dim3(256), 0, s, T.p, nepad, ni, lhs.p, rhs.p);
   HIPCHK(hipMemcpyAsync(&host->fail, fail_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (upload_rest) {      // the device is busy with the Schur stage: now the rest of A, then the symmetry check, on the side stream
+    (*upload_rest)();
+    check_symmetry(side);
+  }
   bool schur_failed = false;
   const std::function<void()> deferred = [&]() {     // after any synchronisation that follows the copies above
+    if (upload_rest) HIPCHK(hipStreamSynchronize(side));
     double amax, asym;
     std::memcpy(&amax, &host->sym[0], sizeof amax);
     std::memcpy(&asym, &host->sym[1], sizeof asym);
@@ -1935,6 +2005,8 @@ bool dense_mixed_constraints_device(hipStream_t s, int N, const double *dA_in, c
   if (w) std::memcpy(w, xwh.data() + N, (size_t)N * sizeof(double));
   return true;
 }
+
+}  // namespace
 
 
 // ---- lcp::SolveLCP_BoxSchur (toolkit/lcp.cc:627-747) -------------------------------------------------
