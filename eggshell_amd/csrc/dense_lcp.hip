@@ -725,13 +725,17 @@ struct MurtyState {       // block-rule and best-iterate memory, device resident
   int have_best, pad;
 };
 
-__global__ void murty_init_kernel(int n, const double *b, const double *lo, uint8_t *S, double *Cb, double *x, double *w,
-                                  double *r, double *bx, double *bw, MurtyState *st) {
+// guess: the block rule may start from any set.  A row whose bound is 0 on the side b points away from (lo = 0 and
+// b <= 0: x = 0, w = -b >= 0 is consistent on its own) starts outside S at that bound instead of inside: on the N = 2048
+// problem the first system has 470 rows instead of 985 and the rule needs 6 pivots instead of 8.
+__global__ void murty_init_kernel(int n, const double *b, const double *lo, const double *hi, int guess, uint8_t *S, double *Cb, double *x,
+                                  double *w, double *r, double *bx, double *bw, MurtyState *st) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) { st->best_ninf = n + 1; st->patience = 10; st->best_good = 0.0; st->have_best = 0; st->pad = 0; }
   if (i < n) {
     const double nb = -b[i];
-    S[i] = 1; Cb[i] = lo[i]; x[i] = 0.0; w[i] = nb; r[i] = nb; bx[i] = 0.0; bw[i] = nb;
+    const bool at_lo = guess && lo[i] == 0.0 && b[i] <= 0.0, at_hi = guess && !at_lo && hi[i] == 0.0 && b[i] >= 0.0;
+    S[i] = (at_lo || at_hi) ? 0 : 1; Cb[i] = at_hi ? hi[i] : lo[i]; x[i] = 0.0; w[i] = nb; r[i] = nb; bx[i] = 0.0; bw[i] = nb;
   }
 }
 
@@ -1578,6 +1582,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   Buf<MurtyState> st_d(1);
   // bordered pivots (see border_* kernels): the base set of the last factorisation and the work arrays
   static const bool border_on = [] { const char *e = std::getenv("EGS_DENSE_BORDER"); return !(e && std::atoi(e) == 0); }();
+  static const bool start_guess = [] { const char *e = std::getenv("EGS_DENSE_GUESS"); return !(e && std::atoi(e) == 0); }();
   const bool track_base = border_on && n <= 2048;      // (the forward product keeps n / 64 partial copies of Y)
   Buf<int> pos0(track_base ? n : 0), idx0(track_base ? npad_max : 0), Dl(track_base ? kBorderMax : 0), Rl(track_base ? kBorderMax : 0);
   Buf<double> Um(track_base ? (size_t)npad_max * kBorderStride : 0), Ym(track_base ? (size_t)npad_max * kBorderStride : 0),
@@ -1596,7 +1601,8 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
   }
   HIPCHK(hipMemsetAsync(fail_d.p, 0, sizeof(int), s));
   // x = 0, w = -b, r = A x - b = -b   (lcp.cc:184-185); S = everything, C = lo
-  hipLaunchKernelGGL(murty_init_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, lo_d, S_d.p, Cb.p, dx, dw, r.p, bx.p, bw.p, st_d.p);
+  hipLaunchKernelGGL(murty_init_kernel, dim3(grid1(n)), dim3(256), 0, s, n, db, lo_d, hi_d, (block && start_guess) ? 1 : 0, S_d.p, Cb.p, dx,
+                     dw, r.p, bx.p, bw.p, st_d.p);
   const int flip_mode = block ? 2 : 1;
   // check the iterate on the device, flip for the next pivot there too, and read the 64-byte record
   auto advance = [&](int mode, double tol, int keep_best) {

@@ -390,6 +390,150 @@ __device__ __forceinline__ void tile_v4(const double *sB, double *sL, double *sR
   inverse_rest_and_store(sL, sX, sQ, Tout, ld, inv);
 }
 
+__device__ __forceinline__ void inverse_rest_and_store_v6(const double *sL, double *sX, double *sQ, const double *sRv, double *Tout, int ld, double *inv, int *fail) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  STAMP(1);
+  lds_barrier();
+  STAMP(2);
+  // L is final: its stores drain while the matrix cores finish the inverse; a pivot that was not positive left a NaN or
+  // an infinity in its reciprocal square root
+  if (wave == 4) {      // the fifth wavefront has nothing else left to do
+    for (int r = 0; r < NB; ++r) if (lane <= r) Tout[(size_t)r * ld + lane] = sL[lane * LS + r];
+  }
+  if (threadIdx.x < NB) { const double rv = sRv[threadIdx.x]; if (!(rv > 0.0) || !(rv < 1.0e300)) atomicOr(fail, 1); }
+  const int li = lane & 15, lk = lane >> 4;
+  // level 1: X(2p+1, 2p) = -X(2p+1, 2p+1) (L(2p+1, 2p) X(2p, 2p)), p = wavefront 0, 1
+  if (wave < 2) {
+    const int o = 32 * wave;
+    double4_t P = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) P = mfma4(sL[(o + 4 * kk + lk) * LS + o + 16 + li], sX[(o + 4 * kk + lk) * XS + o + li], P);
+    double *sP = sQ + wave * 16 * QS;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sP[(lk + 4 * reg) * QS + li] = P[reg];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    double4_t D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) D = mfma4(sX[(o + 16 + li) * XS + o + 16 + 4 * kk + lk], sP[(4 * kk + lk) * QS + li], D);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sX[(o + 16 + lk + 4 * reg) * XS + o + li] = -D[reg];
+  }
+  lds_barrier();
+  // level 2: X_BL = -X_BR (L_BL X_TL), 32 x 32 blocks, one 16 x 16 tile per wavefront
+  if (wave < 4) {
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t Q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) Q = mfma4(sL[(4 * kk + lk) * LS + 32 + 16 * ti + li], sX[(4 * kk + lk) * XS + 16 * tj + li], Q);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sQ[(16 * ti + lk + 4 * reg) * QS + 16 * tj + li] = Q[reg];
+  }
+  lds_barrier();
+  if (wave < 4) {
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_t D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) D = mfma4(sX[(32 + 16 * ti + li) * XS + 32 + 4 * kk + lk], sQ[(4 * kk + lk) * QS + 16 * tj + li], D);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sX[(32 + 16 * ti + lk + 4 * reg) * XS + 16 * tj + li] = -D[reg];
+  }
+  lds_barrier();
+  STAMP(3);
+  for (int i = threadIdx.x; i < NB * NB; i += blockDim.x) {
+    const int r = i >> 6, c = i & 63;
+    inv[i] = sX[r * XS + c];
+  }
+}
+
+
+template <bool NEWTON1, bool SCHED>
+__device__ __forceinline__ void tile_v6(const double *sB, double *sL, double *sRv, double *sX, double *sQ, double *Tout, int ld, double *inv, int *fail) {
+  constexpr int GW = 4, NG = NB / GW, MG = NG / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < NB * XS; i += blockDim.x) sX[i] = 0.0;
+  STAMP(0);
+  if (wave < 4) {
+    double a[MG][GW];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+      for (int q = 0; q < GW; ++q) a[m][q] = sB[lane * kStageLd + GW * (4 * m + wave) + q];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int mo = g >> 2, c0 = GW * g;
+      TR(0);
+      if (wave == (g & 3)) {
+        // the mini-block, lower triangle: m[r][c] from lane c0 + r
+        const double m00 = readlane_f64(a[mo][0], c0);
+        const double m10 = readlane_f64(a[mo][0], c0 + 1), m11 = readlane_f64(a[mo][1], c0 + 1);
+        const double m20 = readlane_f64(a[mo][0], c0 + 2), m21 = readlane_f64(a[mo][1], c0 + 2), m22 = readlane_f64(a[mo][2], c0 + 2);
+        const double m30 = readlane_f64(a[mo][0], c0 + 3), m31 = readlane_f64(a[mo][1], c0 + 3), m32 = readlane_f64(a[mo][2], c0 + 3),
+                     m33 = readlane_f64(a[mo][3], c0 + 3);
+        const double r0 = rsq_pick<NEWTON1>(m00);
+        const double x0 = a[mo][0] * r0;
+        const double l10 = m10 * r0, l20 = m20 * r0, l30 = m30 * r0;
+        const double d1 = __builtin_fma(-l10, l10, m11);
+        const double r1 = rsq_pick<NEWTON1>(d1);
+        const double x1 = __builtin_fma(-x0, l10, a[mo][1]) * r1;
+        const double l21 = __builtin_fma(-l20, l10, m21) * r1, l31 = __builtin_fma(-l30, l10, m31) * r1;
+        const double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
+        const double r2 = rsq_pick<NEWTON1>(d2);
+        const double x2 = __builtin_fma(-x1, l21, __builtin_fma(-x0, l20, a[mo][2])) * r2;
+        const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * r2;
+        const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
+        const double r3 = rsq_pick<NEWTON1>(d3);
+        const double x3 = __builtin_fma(-x2, l32, __builtin_fma(-x1, l31, __builtin_fma(-x0, l30, a[mo][3]))) * r3;
+        sL[(c0 + 0) * LS + lane] = x0; sL[(c0 + 1) * LS + lane] = x1; sL[(c0 + 2) * LS + lane] = x2; sL[(c0 + 3) * LS + lane] = x3;
+        if (lane == 0) { sRv[c0] = r0; sRv[c0 + 1] = r1; sRv[c0 + 2] = r2; sRv[c0 + 3] = r3; }
+      }
+      TR(1);
+      lds_barrier();
+      TR(2);
+      if (g + 1 < NG) {
+        double lrow[GW];
+#pragma unroll
+        for (int q = 0; q < GW; ++q) lrow[q] = sL[(c0 + q) * LS + lane];
+#pragma unroll
+        for (int m = mo; m < MG; ++m) {
+          // (a group that is already factored takes the update too: its registers are dead, and the code stays free of
+          //  wavefront-dependent branches)
+          const int cg = GW * (4 * m + wave);
+#pragma unroll
+          for (int q2 = 0; q2 < GW; ++q2) {
+            double acc = a[m][q2];
+#pragma unroll
+            for (int q = 0; q < GW; ++q) acc = __builtin_fma(-lrow[q], sL[(c0 + q) * LS + cg + q2], acc);
+            a[m][q2] = acc;
+          }
+          if (SCHED) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
+    double acc[16];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      lds_barrier();
+#pragma unroll
+      for (int q = 0; q < GW; ++q) {
+        const int R = GW * g + q, b = R >> 4, r = R & 15;
+        if (r == 0) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+        }
+        if (lane < 16) {
+          const double x = (((lane == r) ? 1.0 : 0.0) - acc[r]) * sRv[R];
+          sX[R * XS + 16 * b + lane] = x;
+#pragma unroll
+          for (int k2 = r + 1; k2 < 16; ++k2) acc[k2] = __builtin_fma(sL[R * LS + 16 * b + k2], x, acc[k2]);
+        }
+      }
+    }
+  }
+  inverse_rest_and_store_v6(sL, sX, sQ, sRv, Tout, ld, inv, fail);
+}
+
 // ---- V5: V4 with the sixteen steps rolled into four rounds of four (one round = each wavefront factors one of its
 // groups; its registers are then shifted down so that the current group is always a[0]): a quarter of the code, and
 // rounds 2..4 run from a warm instruction cache. ----
@@ -510,6 +654,7 @@ __global__ void __launch_bounds__(320) bench_kernel(const double *A, double *Tou
     if (VARIANT == 8) tile_v4<false, true>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
     if (VARIANT == 11) tile_v4<false, false>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
     if (VARIANT == 12) tile_v4<true, true>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
+    if (VARIANT == 13) tile_v6<false, false>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
     if (VARIANT == 9) tile_v5<false>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
     if (VARIANT == 10) tile_v5<true>(sB, sL, sRv, sX, sQ, Tout, NB, inv, fail);
     __syncthreads();
@@ -567,6 +712,7 @@ int main() {
       if (variant == 9) hipLaunchKernelGGL(bench_kernel<9>, dim3(1), dim3(320), 0, 0, dA, dT, dI, dF, reps, dC);
       if (variant == 11) hipLaunchKernelGGL(bench_kernel<11>, dim3(1), dim3(320), 0, 0, dA, dT, dI, dF, reps, dC);
       if (variant == 12) hipLaunchKernelGGL(bench_kernel<12>, dim3(1), dim3(320), 0, 0, dA, dT, dI, dF, reps, dC);
+      if (variant == 13) hipLaunchKernelGGL(bench_kernel<13>, dim3(1), dim3(320), 0, 0, dA, dT, dI, dF, reps, dC);
       if (variant == 10) hipLaunchKernelGGL(bench_kernel<10>, dim3(1), dim3(320), 0, 0, dA, dT, dI, dF, reps, dC);
       CHK(hipDeviceSynchronize());
       long long c1;
@@ -612,5 +758,6 @@ int main() {
   run(10, "v5 + one-Newton rsqrt", true);
   run(11, "v4 without sched barriers", true);
   run(12, "v4 + one-Newton rsqrt", true);
+  run(13, "v6 = v4, no per-step checks, L stored early", true);
   return 0;
 }
