@@ -514,6 +514,7 @@ void launch_solve_t(egs_problem *p, int method, REAL cfm, REAL kscale, int sweep
       a.wsB0 = reinterpret_cast<REAL *>(p->wsB0.p); a.wsB1 = reinterpret_cast<REAL *>(p->wsB1.p);
       a.wsD = reinterpret_cast<REAL *>(p->wsD.p); a.wsInv = reinterpret_cast<REAL *>(p->wsInv.p);
       launch_cons_prepare<REAL>(a, ctx->stream);
+      a.patch_runs = p->plan.patch_runs ? 1 : 0;
       launch_quad_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
     } else {
       launch_patch_solve<REAL>(a, method, p->plan.n_patch_tiles, p->gtickets.p, ctx->stream);
@@ -1094,6 +1095,10 @@ void ensure_tile_plan(egs_problem *p) {
     const int occ_glob = pl.global.empty() ? 1 : (f32 ? occupancy_global_solve<float>() : occupancy_global_solve<double>());
     p->oversize = choose_oversize_schedule(pl.n_patch_tiles, occ_quad, occ_lane, p->ctx->cu_count, !(pe && std::atoi(pe) == 0),
                                            pl.block == 256 && !(qp && std::atoi(qp) == 0));
+    // (a patch plan with runs is for the 4-lane kernel only: plan.cpp builds it when that kernel will take it; should it
+    //  not -- no LDS left for a resident workgroup -- the island goes the all-global way rather than to a kernel that
+    //  does not know the placeholders)
+    if (pl.patch_runs && p->oversize == kLanePatches) p->oversize = kAllGlobal;
     p->global_max_blocks = std::max(1, std::min(occ_glob, 1) * p->ctx->cu_count);
     if (p->oversize == kQuadPatches) {
       const size_t rsz = p->real_size(), mm2 = (size_t)m;

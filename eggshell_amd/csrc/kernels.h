@@ -37,6 +37,7 @@ struct SolveArgs {
   const int32_t *tile_period = nullptr, *tile_depth = nullptr;
   int32_t n_tiles = 0;
   int32_t runs = 0;            // the timetable counts groups of four constraints (plan.h: Plan::runs)
+  int32_t patch_runs = 0;      // body patches: the lanes come in chunks of four quads (Plan::patch_runs, quad_solve.hip)
   int iso = 0;              // 1: every M^-1 block is diag(a,a,a,b,b,b): B is formed on the fly (tile kernel)
   // Per-sweep history (tolerance-terminated solves): x after sweep s and each body's
   // accumulator once its last constraint of sweep s has run, s = 1..sweeps of this launch.

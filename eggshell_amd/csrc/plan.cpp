@@ -37,7 +37,7 @@ int g_patch_workgroups = 256;     // CUs of the device the plans are built for (
 
 void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t *body1,
                    const std::vector<int32_t> &cnt, const std::vector<int32_t> &pos0,
-                   const std::vector<int32_t> &pos1) {
+                   const std::vector<int32_t> &pos1, bool allow_runs) {
   const int block = plan.block;
   const int mg = (int)plan.global.size();
   // head-room for the idle lanes that align the lane groups to wavefronts (below)
@@ -59,17 +59,42 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
   }
   // owner body of a constraint = its first real body
   auto owner = [&](int c) { return body0[c] >= 0 ? body0[c] : body1[c]; };
-  std::vector<int32_t> owned(n_bodies, 0);
+  // Runs (plan.h): consecutive constraints on the same two bodies -- the contact points of a box face -- in chunks of at
+  // most four.  A chunk takes four adjacent lane slots of the 4-lane patch kernel (one DPP row: members in list order,
+  // then placeholders, cidx = -2, with the chunk's slots) and is ONE node of the ticket protocol: its quads wait for
+  // the first member's ticket, the accumulators go from member to member through the row (row_shr:4) and the last
+  // slot publishes ticket = last member's + 1.  Only for the 4-lane kernel, and while less than a quarter of the
+  // slots would be placeholders.
+  std::vector<int32_t> chunk_of(mg, 0), chunk_first, chunk_len;
+  {
+    const char *re = std::getenv("EGS_PATCH_RUNS"), *qp = std::getenv("EGS_QUAD_PATCH");
+    plan.patch_runs = allow_runs && block == 256 && !(re && std::atoi(re) == 0) && !(qp && std::atoi(qp) == 0);
+    if (plan.patch_runs) {
+      for (int g = 0; g < mg; ++g) {
+        const int c = plan.global[g].cidx, cp = g > 0 ? plan.global[g - 1].cidx : -1;
+        const bool same = g > 0 && body0[c] == body0[cp] && body1[c] == body1[cp] && chunk_len.back() < 4 &&
+                          (body0[c] < 0 || pos0[c] == pos0[cp] + 1) && (body1[c] < 0 || pos1[c] == pos1[cp] + 1);
+        if (!same) { chunk_first.push_back(g); chunk_len.push_back(0); }
+        chunk_of[g] = (int32_t)chunk_len.size() - 1;
+        ++chunk_len.back();
+      }
+      if (4L * (long)chunk_len.size() > (5L * mg) / 4) { plan.patch_runs = false; chunk_first.clear(); chunk_len.clear(); }
+    }
+  }
+  const bool runs = plan.patch_runs;
+  const int n_chunks = (int)chunk_len.size();
+  std::vector<int32_t> owned(n_bodies, 0);             // lane slots a body's constraints take
   std::vector<std::vector<int32_t>> touch(n_bodies);   // body -> global-list positions of its constraints
   std::vector<char> in_big(n_bodies, 0);
   for (int g = 0; g < mg; ++g) {
     const int c = plan.global[g].cidx;
     if (owner(c) < 0) return;                  // world-world constraint in an oversize island: cannot happen
-    ++owned[owner(c)];
+    if (!runs) ++owned[owner(c)];
+    else if (chunk_first[chunk_of[g]] == g) owned[owner(c)] += 4;
     for (int b : {body0[c], body1[c]})
       if (b >= 0) { touch[b].push_back(g); in_big[b] = 1; if (cnt[b] > 65535) return; }
   }
-  for (int b = 0; b < n_bodies; ++b) if (owned[b] > block) return;
+  for (int b = 0; b < n_bodies; ++b) if (owned[b] > block) { plan.patch_runs = false; return; }
   // Two ways to cut the island's bodies into patches; the one whose WORST body crosses patches least often per sweep
   // is taken (then the fewer crossings in total).  A body's constraint list is walked cyclically every sweep and every
   // change of patch along it is a hand-off through global memory (~4 us against 0.2-0.4 us in LDS), so the busiest
@@ -192,29 +217,61 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     }
   }
   bool overflow = false;
-  for (int g = 0; g < mg; ++g) {              // list order -> lanes ascending by list index
-    const int c = plan.global[g].cidx;
-    const int t = renum[patch_of[owner(c)]];
-    auto slot = [&](int b, int side) -> uint16_t {
-      if (b < 0) return 0;
-      int sl = -1;
-      if (shared[b]) {
-        for (auto &ps : shared_slot[b]) if (ps.first == t) sl = ps.second;
-        if (sl < 0) { sl = plan.patch_tile_nslots[t]++; shared_slot[b].emplace_back(t, sl); tile_bodies[t].push_back(-(b + 2)); }
-      } else {
-        if (slot_of[b] < 0) { slot_of[b] = plan.patch_tile_nslots[t]++; tile_bodies[t].push_back(b); }
-        sl = slot_of[b];
+  auto slot_number = [&](int b, int t) -> int {
+    if (b < 0) return 0;
+    int sl = -1;
+    if (shared[b]) {
+      for (auto &ps : shared_slot[b]) if (ps.first == t) sl = ps.second;
+      if (sl < 0) { sl = plan.patch_tile_nslots[t]++; shared_slot[b].emplace_back(t, sl); tile_bodies[t].push_back(-(b + 2)); }
+    } else {
+      if (slot_of[b] < 0) { slot_of[b] = plan.patch_tile_nslots[t]++; tile_bodies[t].push_back(b); }
+      sl = slot_of[b];
+    }
+    if (sl >= (int)kSlotMask) overflow = true;
+    return sl;
+  };
+  // the lane group of an entry (see below): 0 = waits on another patch in a forward sweep, 1 = only in a backward one
+  // (or runs the launch-boundary code of a shared body), 2 = interior
+  std::vector<uint8_t> entry_group((size_t)np * block, 2);
+  auto shared_end = [&](int b, unsigned pos, unsigned cn) { return b >= 0 && shared[b] && (pos == 0u || pos + 1u == cn); };
+  if (!runs) {
+    for (int g = 0; g < mg; ++g) {              // list order -> lanes ascending by list index
+      const int c = plan.global[g].cidx;
+      const int t = renum[patch_of[owner(c)]];
+      LaneDesc d;
+      d.cidx = c;
+      d.slot0 = (uint16_t)(slot_number(body0[c], t) | side_flags[(size_t)g * 2 + 0]);
+      d.slot1 = (uint16_t)(slot_number(body1[c], t) | side_flags[(size_t)g * 2 + 1]);
+      d.pos0 = (uint16_t)pos0[c]; d.cnt0 = (uint16_t)(body0[c] >= 0 ? cnt[body0[c]] : 0);
+      d.pos1 = (uint16_t)pos1[c]; d.cnt1 = (uint16_t)(body1[c] >= 0 ? cnt[body1[c]] : 0);
+      const int f = d.slot0 | d.slot1;
+      entry_group[(size_t)t * block + fill[t]] =
+          (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : ((shared_end(body0[c], d.pos0, d.cnt0) || shared_end(body1[c], d.pos1, d.cnt1)) ? 1 : 2);
+      plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
+    }
+  } else {
+    for (int q = 0; q < n_chunks; ++q) {        // list order, four slots per chunk
+      const int g0 = chunk_first[q], len = chunk_len[q], c0 = plan.global[g0].cidx, cl = plan.global[g0 + len - 1].cidx;
+      const int t = renum[patch_of[owner(c0)]];
+      // the chunk's ends decide where its accumulators come from and go to
+      const uint16_t f0 = (uint16_t)((side_flags[(size_t)g0 * 2 + 0] & kPrevRemote) | (side_flags[(size_t)(g0 + len - 1) * 2 + 0] & kNextRemote));
+      const uint16_t f1 = (uint16_t)((side_flags[(size_t)g0 * 2 + 1] & kPrevRemote) | (side_flags[(size_t)(g0 + len - 1) * 2 + 1] & kNextRemote));
+      const int s0 = slot_number(body0[c0], t), s1 = slot_number(body1[c0], t);
+      const unsigned cn0 = body0[c0] >= 0 ? cnt[body0[c0]] : 0, cn1 = body1[c0] >= 0 ? cnt[body1[c0]] : 0;
+      const int f = f0 | f1;
+      const bool ends = (body0[c0] >= 0 && shared[body0[c0]] && (pos0[c0] == 0 || (unsigned)pos0[cl] + 1u == cn0)) ||
+                        (body1[c0] >= 0 && shared[body1[c0]] && (pos1[c0] == 0 || (unsigned)pos1[cl] + 1u == cn1));
+      const uint8_t grp = (f & kPrevRemote) ? 0 : (f & kNextRemote) ? 1 : (ends ? 1 : 2);
+      for (int k = 0; k < 4; ++k) {
+        LaneDesc d;
+        d.cidx = k < len ? plan.global[g0 + k].cidx : -2;
+        d.slot0 = (uint16_t)(s0 | f0); d.slot1 = (uint16_t)(s1 | f1);
+        d.pos0 = (uint16_t)(pos0[c0] + k); d.cnt0 = (uint16_t)cn0;
+        d.pos1 = (uint16_t)(pos1[c0] + k); d.cnt1 = (uint16_t)cn1;
+        entry_group[(size_t)t * block + fill[t]] = grp;
+        plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
       }
-      if (sl >= (int)kSlotMask) overflow = true;
-      return (uint16_t)(sl | side_flags[(size_t)g * 2 + side]);
-    };
-    LaneDesc d;
-    d.cidx = c;
-    d.slot0 = slot(body0[c], 0);
-    d.slot1 = slot(body1[c], 1);
-    d.pos0 = (uint16_t)pos0[c]; d.cnt0 = (uint16_t)(body0[c] >= 0 ? cnt[body0[c]] : 0);
-    d.pos1 = (uint16_t)pos1[c]; d.cnt1 = (uint16_t)(body1[c] >= 0 ? cnt[body1[c]] : 0);
-    plan.patch_lanes[(size_t)t * block + fill[t]++] = d;
+    }
   }
   // Lanes that wait on ANOTHER patch (a side whose list-order neighbour is remote) poll global memory: a look costs a
   // memory round trip (~1-2 us) and stalls the whole wavefront, i.e. every constraint that shares it, including those
@@ -229,24 +286,22 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     //  with a polling one, so its own LDS hand-off is seen at once and not at the polling wavefront's next look.)
     // (the first and the last constraint of a SHARED body's list also run the cross-patch code -- the launch-boundary
     //  cases of the kernels -- although they never poll: they go with the second group)
-    auto shared_end = [&](int b, unsigned pos, unsigned cn) { return b >= 0 && shared[b] && (pos == 0u || pos + 1u == cn); };
-    auto group = [&](const LaneDesc &d) {
-      const int f = d.slot0 | d.slot1;
-      if (f & kPrevRemote) return 0;
-      if (f & kNextRemote) return 1;
-      return (shared_end(body0[d.cidx], d.pos0, d.cnt0) || shared_end(body1[d.cidx], d.pos1, d.cnt1)) ? 1 : 2;
-    };
     std::vector<LaneDesc> tmp;
+    std::vector<int> order;
     for (int t = 0; t < np; ++t) {
       LaneDesc *base = plan.patch_lanes.data() + (size_t)t * block;
-      std::stable_sort(base, base + fill[t], [&](const LaneDesc &a, const LaneDesc &b) { return group(a) < group(b); });
+      const uint8_t *grp = entry_group.data() + (size_t)t * block;
+      order.resize(fill[t]);
+      for (int k = 0; k < fill[t]; ++k) order[k] = k;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return grp[a] < grp[b]; });     // (a chunk's four entries stay together)
       int n0 = 0, n1 = 0;
-      for (int k = 0; k < fill[t]; ++k) { n0 += group(base[k]) == 0; n1 += group(base[k]) == 1; }
+      for (int k = 0; k < fill[t]; ++k) { n0 += grp[k] == 0; n1 += grp[k] == 1; }
       const int unit = 16;
       const int s1 = (n0 + unit - 1) / unit * unit, s2 = s1 + (n1 + unit - 1) / unit * unit;
       const int total = s2 + (fill[t] - n0 - n1);
       if (total > block || (n0 == 0 && n1 == 0)) continue;
-      tmp.assign(base, base + fill[t]);
+      tmp.resize(fill[t]);
+      for (int k = 0; k < fill[t]; ++k) tmp[k] = base[order[k]];
       std::fill(base, base + block, idle);
       std::copy(tmp.begin(), tmp.begin() + n0, base);
       std::copy(tmp.begin() + n0, tmp.begin() + n0 + n1, base + s1);
@@ -282,7 +337,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     plan.max_period = plan.max_depth = 1; plan.levels_ok = true; plan.runs = false;
     plan.tile_nslots.clear(); plan.tile_slot_off.clear(); plan.slot_body.clear();
     plan.global.clear();
-    plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0;
+    plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0; plan.patch_runs = false;
     plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear(); plan.patch_slot_body.clear();
   }
   plan.n = n_bodies; plan.m = m; plan.block = block;
@@ -673,7 +728,16 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     g.pos1 = pos1[i]; g.cnt1 = body1[i] >= 0 ? cnt[body1[i]] : 0;
     plan.global.push_back(g);
   }
-  if (!plan.global.empty()) build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1);
+  if (!plan.global.empty()) {
+    build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1, true);
+    if (plan.patch_runs && plan.n_patch_tiles > g_patch_workgroups) {
+      // more patches than the 4-lane kernel can keep resident: the 1-lane patch kernel will run them, which knows no runs
+      plan.n_patch_tiles = 0; plan.patch_max_slots = 1; plan.n_shared_bodies = 0; plan.patch_runs = false;
+      plan.patch_lanes.clear(); plan.patch_tile_nslots.clear(); plan.patch_tile_slot_off.clear(); plan.patch_slot_body.clear();
+      build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1, false);
+    }
+    if (plan.n_patch_tiles == 0) plan.patch_runs = false;
+  }
   return plan;
 }
 

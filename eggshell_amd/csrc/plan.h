@@ -74,6 +74,9 @@ struct Plan {
   std::vector<LaneDesc> patch_lanes;        // n_patch_tiles * block
   std::vector<int32_t> patch_tile_nslots, patch_tile_slot_off, patch_slot_body;
   int n_shared_bodies = 0;
+  // patch_lanes hold chunks of up to four consecutive constraints on the same two bodies, four slots each (members,
+  // then placeholders with cidx = -2): see build_patches.  Only the 4-lane patch kernel understands them.
+  bool patch_runs = false;
 };
 
 constexpr uint16_t kSlotMask = 0x3FFF;     // LDS slot number of a patch lane's side

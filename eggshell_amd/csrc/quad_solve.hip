@@ -146,7 +146,13 @@ __device__ __forceinline__ bool gran_poll3(const Gran *p, unsigned long long tag
 // finished).
 // HIST = true: records the per-sweep snapshots of SolveArgs::hist_x / hist_acc (tolerance-
 // terminated solves); a separate instantiation, so the plain kernel keeps its 96 VGPRs.
-template <typename REAL, int METHOD, int QT, bool PATCH, bool HIST>
+// RUNS = true (patches only, Plan::patch_runs): the lanes come in chunks of four quads = one DPP row: up to four consecutive
+// constraints on the same two bodies (members, then placeholders with cidx = -2 that carry the chunk's slots).  A chunk is
+// ONE node of the ticket protocol: its quads wait for the first member's ticket (pos and want are the FIRST member's on
+// every slot, see below), the accumulators go from member to member through the row (row_shr:4, backward row_shl:4)
+// and the slot at the end publishes the last member's ticket + 1.  Same updates, same order, same bits -- three of
+// four hand-offs on such a body no longer go through LDS.
+template <typename REAL, int METHOD, int QT, bool PATCH, bool HIST, bool RUNS = false>
 __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL> A, uint32_t *g_tick) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   REAL *s_acc = reinterpret_cast<REAL *>(smem);
@@ -165,13 +171,22 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
 
   const LaneDesc d = A.lanes[(size_t)tile * QT + (tid >> 2)];
   const bool active = d.cidx >= 0;
+  const bool chain = RUNS ? d.cidx != -1 : active;      // RUNS: placeholders take part in the hand-off
+  const int run_pos = (tid >> 2) & 3;                   // RUNS: this quad's place in its chunk
+  int run_len = 1;                                      // RUNS: members of the chunk
+  if (RUNS) {
+    const unsigned long long act = __ballot(active);
+    run_len = __popcll((act >> (tid & 48)) & 0xffffull) >> 2;
+  }
   const int raw_slot = side ? d.slot1 : d.slot0;
-  const bool has = active && raw_slot != 0;        // this lane's body is a real body
+  const bool has = chain && raw_slot != 0;         // this lane's body is a real body
   const int slot = PATCH ? (raw_slot & kSlotMask) : raw_slot;
   // ... shared with other workgroups: where its list-order neighbours on the body live
   const bool prev_remote = PATCH && has && (raw_slot & kPrevRemote) != 0, next_remote = PATCH && has && (raw_slot & kNextRemote) != 0;
   const bool sh = PATCH && has && slot_body[slot] < -1;
-  const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = side ? d.pos1 : d.pos0;
+  // RUNS: the chunk's FIRST member's position on every slot (the plan stores first + place)
+  const unsigned cnt = side ? d.cnt1 : d.cnt0, pos = (side ? d.pos1 : d.pos0) - (RUNS ? (unsigned)run_pos : 0u);
+  const unsigned nrun = RUNS ? (unsigned)run_len : 1u;
   REAL *my_acc = s_acc + slot * 6 + 3 * half;      // slot 0 (world) stays zero
   unsigned *my_tick = s_tick + slot;
   REAL *g_acc = A.acc;
@@ -180,7 +195,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   const bool gran = PATCH && A.gran != nullptr;      // uniform
   const unsigned long long epoch_hi = (unsigned long long)A.gran_epoch << 32;
   if (sh) {   // where the accumulator crosses between patches
-    const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
+    const int body = -slot_body[slot] - 2;      // (a shared body's slot holds -(body + 2))
     g_acc = A.acc + (size_t)body * 6 + 3 * half;
     g_t = g_tick + body;
     my_gran = reinterpret_cast<Gran *>(A.gran) + (size_t)body * 6 + half;     // [component][half]
@@ -229,10 +244,11 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     // list order: the value comes from global memory if the predecessor on the body is remote
     // (pos 0: both places hold zeros) and goes there if the successor is
     // (a launch without sweeps ends here: then the body's last update goes to global memory)
-    const bool acq = prev_remote, rel = next_remote || (sh && A.sweeps == 0 && pos == cnt - 1u);
+    const bool acq = prev_remote, rel = next_remote || (sh && A.sweeps == 0 && pos + nrun == cnt);
     // granules: the body's first update starts from zero (nobody wrote before it); a launch without sweeps leaves the
     // last value in A.acc, where the next launch and the follow-up kernels look for it
-    const bool acq_g = gran && acq && pos != 0u, end_g = gran && sh && A.sweeps == 0 && pos == cnt - 1u;
+    const bool acq_g = gran && acq && pos != 0u, end_g = gran && sh && A.sweeps == 0 && pos + nrun == cnt;
+    const bool end_slot = !RUNS || run_pos == 3;      // RUNS: the slot the chunk's last value ends up in
     while (pending) {
       REAL ga[3] = {REAL(0), REAL(0), REAL(0)};
       unsigned t;
@@ -252,29 +268,40 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = my_acc[k];
         }
+        // (RUNS: the lanes of a chunk's row with this q see the same ticket at the same look, so all four are here)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          REAL u = tfma(Bh[3 * k + 0], x[0], a[k]);
-          u = tfma(Bh[3 * k + 1], x[1], u);
-          a[k] = tfma(Bh[3 * k + 2], x[2], u);
+        for (int sub = 0; sub < (RUNS ? 4 : 1); ++sub) {
+          if (RUNS && sub > 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] = dpp<0x114>(a[k]);      // row_shr:4 = the same quarter of the previous member
+          }
+          if (!RUNS || (run_pos == sub && active)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              REAL u = tfma(Bh[3 * k + 0], x[0], a[k]);
+              u = tfma(Bh[3 * k + 1], x[1], u);
+              a[k] = tfma(Bh[3 * k + 2], x[2], u);
+            }
+          }
         }
-        if (gran && rel) {
+        if (!end_slot) {
+        } else if (gran && rel) {
           if (end_g) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gst(g_acc + k, a[k]);
           } else {
-            gran_store3<REAL>(my_gran, a, epoch_hi | (pos + 1u));
+            gran_store3<REAL>(my_gran, a, epoch_hi | (pos + nrun));
           }
         } else if (rel) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) gst(g_acc + k, a[k]);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both halves' stores (one wavefront) have landed
-          if (half == 0) gst(g_t, pos + 1u);
+          if (half == 0) gst(g_t, pos + nrun);
         } else {
 #pragma unroll
           for (int k = 0; k < 3; ++k) my_acc[k] = a[k];
-          if (half == 0) lds_store_release(my_tick, pos + 1u);
+          if (half == 0) lds_store_release(my_tick, pos + nrun);
         }
         pending = false;
       } else if (++spins > A.spin_limit) {
@@ -286,11 +313,14 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
   }
 
   {
-    const unsigned ord = (METHOD == 2) ? cnt - 1u - pos : pos;
+    const unsigned ord = (METHOD == 2) ? cnt - pos - nrun : pos;      // the node's first update in sweep order
     unsigned want = base + ord;
     int sweep = 1;
     unsigned spins = 0;
-    bool alive = active && A.sweeps >= 1;
+    bool alive = chain && A.sweeps >= 1;
+    const bool end_slot = !RUNS || ((METHOD == 1) ? run_pos == 3 : run_pos == 0);      // where the chunk's last value ends up
+    // this member's own place in the sweep (HIST: the body's last update of the sweep is snapshot)
+    const unsigned ord_m = RUNS ? ((METHOD == 2) ? cnt - 1u - (pos + (unsigned)run_pos) : pos + (unsigned)run_pos) : ord;
     const unsigned tick_addr = lds_addr(my_tick), acc_addr = lds_addr(my_acc);
     // sweep order: forward = list order, backward = reversed, so the neighbours swap roles
     // A wavefront none of whose lanes touches a body that other patches share runs the loop WITHOUT the cross-patch
@@ -301,7 +331,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
     // (a lane needs that code if a list-order neighbour on its body is remote, or if it is the first / last constraint of a
     //  shared body's list: the launch-boundary cases)
     const bool acq_flag = (METHOD == 1) ? prev_remote : next_remote;
-    const bool lane_remote = has && (prev_remote || next_remote || (sh && (pos == 0u || pos == cnt - 1u)));
+    const bool lane_remote = has && (prev_remote || next_remote || (sh && (pos == 0u || pos + nrun == cnt)));
     const bool lane_acquires = has && (acq_flag || (sh && A.resume && ord == 0u));
     // three loops: 0 = no cross-patch code at all, 1 = releases only (stores; no global load, hence no vmcnt wait that
     // would hold the wavefront until its own write-through stores are acknowledged), 2 = everything
@@ -316,7 +346,7 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
       // a shared body's first update of a resumed launch reads global memory, its last update of
       // the launch writes it (the accumulator must not stay behind in some patch's LDS)
       const bool first_of_launch = ACQ && sh && A.resume && sweep == 1 && ord == 0u;
-      const bool last_of_launch = REMOTE && sh && sweep == A.sweeps && ord == cnt - 1u;
+      const bool last_of_launch = REMOTE && sh && sweep == A.sweeps && ord + nrun == cnt;
       const bool acq = acq_side || first_of_launch;
       const bool rel = rel_side || last_of_launch;
       // granules: a predecessor in another patch of THIS launch is polled for; at the launch boundary the value is in A.acc
@@ -339,73 +369,97 @@ __global__ void __launch_bounds__(4 * QT) quad_solve_kernel(const SolveArgs<REAL
 #pragma unroll
           for (int k = 0; k < 3; ++k) a[k] = gld(g_acc + k);
         }
-        REAL res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
+        // one update of this lane's constraint: `v` = its quarter of the body's accumulator, in and out
+        auto update = [&](REAL (&v)[3]) {
+          REAL res[3], dx[3] = {REAL(0), REAL(0), REAL(0)};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          REAL p = Jh[3 * r] * a[0];
-          p = tfma(Jh[3 * r + 1], a[1], p);
-          p = tfma(Jh[3 * r + 2], a[2], p);
-          const REAL full = tfma(A.cfm, x[r], quad_sum(p));
-          res[r] = rhs[r] - full;
-        }
-        if (METHOD == 1) {
-          REAL t0 = res[0];
-          REAL xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
-          dx[0] = xn - x[0]; x[0] = xn;
-          REAL t1 = tfma(-Dl[0], dx[0], res[1]);
-          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
-          dx[1] = xn - x[1]; x[1] = xn;
-          REAL t2 = tfma(-Dl[1], dx[0], res[2]);
-          t2 = tfma(-Dl[2], dx[1], t2);
-          xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
-          dx[2] = xn - x[2]; x[2] = xn;
-        } else {
-          REAL t2 = res[2];
-          REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
-          dx[2] = xn - x[2]; x[2] = xn;
-          REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
-          xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
-          dx[1] = xn - x[1]; x[1] = xn;
-          REAL t0 = tfma(-Dl[1], dx[2], res[0]);                 // D02
-          t0 = tfma(-Dl[0], dx[1], t0);                          // D01
-          xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
-          dx[0] = xn - x[0]; x[0] = xn;
-        }
-        REAL an_hist[3] = {REAL(0), REAL(0), REAL(0)};
-        if (has) {
-          REAL an[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            REAL u = tfma(Bh[3 * k + 0], dx[0], a[k]);
-            u = tfma(Bh[3 * k + 1], dx[1], u);
-            an[k] = tfma(Bh[3 * k + 2], dx[2], u);
-            an_hist[k] = an[k];
+          for (int r = 0; r < 3; ++r) {
+            REAL p = Jh[3 * r] * v[0];
+            p = tfma(Jh[3 * r + 1], v[1], p);
+            p = tfma(Jh[3 * r + 2], v[2], p);
+            const REAL full = tfma(A.cfm, x[r], quad_sum(p));
+            res[r] = rhs[r] - full;
           }
+          if (METHOD == 1) {
+            REAL t0 = res[0];
+            REAL xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
+            dx[0] = xn - x[0]; x[0] = xn;
+            REAL t1 = tfma(-Dl[0], dx[0], res[1]);
+            xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+            dx[1] = xn - x[1]; x[1] = xn;
+            REAL t2 = tfma(-Dl[1], dx[0], res[2]);
+            t2 = tfma(-Dl[2], dx[1], t2);
+            xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+            dx[2] = xn - x[2]; x[2] = xn;
+          } else {
+            REAL t2 = res[2];
+            REAL xn = project(tfma(t2, inv[2], x[2]), lo[2], hi[2]);
+            dx[2] = xn - x[2]; x[2] = xn;
+            REAL t1 = tfma(-Dl[2], dx[2], res[1]);                 // D12
+            xn = project(tfma(t1, inv[1], x[1]), lo[1], hi[1]);
+            dx[1] = xn - x[1]; x[1] = xn;
+            REAL t0 = tfma(-Dl[1], dx[2], res[0]);                 // D02
+            t0 = tfma(-Dl[0], dx[1], t0);                          // D01
+            xn = project(tfma(t0, inv[0], x[0]), lo[0], hi[0]);
+            dx[0] = xn - x[0]; x[0] = xn;
+          }
+          if (has) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              REAL u = tfma(Bh[3 * k + 0], dx[0], v[k]);
+              u = tfma(Bh[3 * k + 1], dx[1], u);
+              v[k] = tfma(Bh[3 * k + 2], dx[2], u);
+            }
+          }
+        };
+        REAL an[3] = {a[0], a[1], a[2]};
+        REAL an_hist[3] = {REAL(0), REAL(0), REAL(0)};
+        if (!RUNS) {
+          update(an);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) an_hist[k] = an[k];
+        } else {
+          // the chunk's updates in sweep order; the accumulators go from quad to quad, LDS (or the other patch) sees
+          // the first read and the last write only
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            if (sub > 0) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) an[k] = (METHOD == 1) ? dpp<0x114>(an[k]) : dpp<0x104>(an[k]);      // row_shr:4 / row_shl:4
+            }
+            if (run_pos == ((METHOD == 1) ? sub : 3 - sub) && active) {
+              update(an);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) an_hist[k] = an[k];
+            }
+          }
+        }
+        if (has && end_slot) {
           if (REMOTE && gran && rel) {
             if (last_of_launch) {
 #pragma unroll
               for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             } else {
-              gran_store3<REAL>(my_gran, an, epoch_hi | (want + 1u));
+              gran_store3<REAL>(my_gran, an, epoch_hi | (want + nrun));
             }
           } else if (REMOTE && rel) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gst(g_acc + k, an[k]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (half == 0) gst(g_t, want + 1u);
+            if (half == 0) gst(g_t, want + nrun);
           } else {
             store3(acc_addr, an);
-            if (half == 0) store_tick(tick_addr, want + 1u);
+            if (half == 0) store_tick(tick_addr, want + nrun);
           }
         }
-        if (PATCH && A.trace != nullptr && q == 0) A.trace[(size_t)(sweep - 1) * A.m + d.cidx] = wall_clock64();
+        if (PATCH && A.trace != nullptr && q == 0 && active) A.trace[(size_t)(sweep - 1) * A.m + d.cidx] = wall_clock64();
         if (HIST) {   // snapshots for the per-sweep stopping test (kernels.h)
-          if (q == 0) {
+          if (q == 0 && active) {
             REAL *hx = A.hist_x + ((size_t)(sweep - 1) * A.m + d.cidx) * 3;
             hx[0] = x[0]; hx[1] = x[1]; hx[2] = x[2];
           }
-          if (has && ord == cnt - 1u) {   // this was the body's last update of the sweep
+          if (has && active && ord_m == cnt - 1u) {   // this was the body's last update of the sweep
             const int body = side ? A.body1[d.cidx] : A.body0[d.cidx];
             REAL *ha = A.hist_acc + ((size_t)(sweep - 1) * A.n_bodies + body) * 6 + 3 * half;
             ha[0] = an_hist[0]; ha[1] = an_hist[1]; ha[2] = an_hist[2];
@@ -728,20 +782,23 @@ void launch_quad_patch_solve(const SolveArgs<REAL> &a, int method, int n_tiles, 
   if (n_tiles <= 0) return;
   const size_t lds = (size_t)a.max_slots * (6 * sizeof(REAL) + sizeof(unsigned));
   const bool hist = a.hist_x != nullptr;
-  if (method == 1) {
-    if (hist) hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 1, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-  } else {
-    if (hist) hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-    else hipLaunchKernelGGL((quad_solve_kernel<REAL, 2, 256, true, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);
-  }
+#define EGS_QPLAUNCH(M, H)                                                                                                      \
+  do {                                                                                                                         \
+    if (a.patch_runs) hipLaunchKernelGGL((quad_solve_kernel<REAL, M, 256, true, H, true>), dim3(n_tiles), dim3(1024), lds, s, a, tickets); \
+    else hipLaunchKernelGGL((quad_solve_kernel<REAL, M, 256, true, H, false>), dim3(n_tiles), dim3(1024), lds, s, a, tickets);             \
+  } while (0)
+  if (method == 1) { if (hist) EGS_QPLAUNCH(1, true); else EGS_QPLAUNCH(1, false); }
+  else { if (hist) EGS_QPLAUNCH(2, true); else EGS_QPLAUNCH(2, false); }
+#undef EGS_QPLAUNCH
 }
 
 template <typename REAL>
 int occupancy_quad_patch_solve(size_t lds) {
   int best = 1 << 30, nb = 0;
 #define EGS_OCC(M, H)                                                                                     \
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, quad_solve_kernel<REAL, M, 256, true, H>, 1024, lds) != hipSuccess) return 0; \
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, quad_solve_kernel<REAL, M, 256, true, H, false>, 1024, lds) != hipSuccess) return 0; \
+  best = nb < best ? nb : best;                                                                           \
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, quad_solve_kernel<REAL, M, 256, true, H, true>, 1024, lds) != hipSuccess) return 0;  \
   best = nb < best ? nb : best;
   EGS_OCC(1, true) EGS_OCC(1, false) EGS_OCC(2, true) EGS_OCC(2, false)
 #undef EGS_OCC
