@@ -108,3 +108,36 @@ def test_tolerance_terminated_patches_stop_where_the_reference_stops(ctx, method
         assert st.iterations == it, (cfm, tol, limit)
         assert np.array_equal(x, xf) and np.array_equal(a, af)
         assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+
+
+@pytest.mark.parametrize("method", [capi.GAUSS_SEIDEL, capi.SOR])
+def test_runs_inside_patches(ctx, method, monkeypatch):
+    """Chunks of up to four consecutive constraints on the same two bodies are ONE ticket node of the 4-lane patch kernel
+    (Plan::patch_runs): full chunks (a box face's four points) and ragged ones (1..8 points per pair: placeholders,
+    runs cut into several chunks), fixed sweep counts, a tolerance-terminated solve (snapshots + resumed launches) and
+    fp32 -- the oracle's bits, with the chunks and without them (EGS_PATCH_RUNS=0)."""
+    from helpers import grouped_system
+    rng = np.random.default_rng(63)
+    base, _ = random_system(rng, 220, 420, world_frac=0.1, connected=True)
+    for rep in (4, "ragged"):
+        s, rhs = grouped_system(rng, base, None, rep)
+        assert s.m > 1200
+        want = {K: orc.fast_iterate(s, rhs, 0.05, method, max_iters=K, tol=0.0) for K in (0, 1, 5, 20)}
+        xt, at, it, _ = orc.fast_iterate(s, rhs, 0.5, method, max_iters=300, tol=1e-9)
+        xo32, ao32, _, _ = orc.fast_iterate_f32(s, rhs, 0.05, method, max_iters=12)
+        for runs in ("1", "0"):
+            monkeypatch.setenv("EGS_PATCH_RUNS", runs)
+            for K, (xf, af, _, rf) in want.items():
+                x, a, st = solve(ctx, s, rhs, 0.05, method, K)
+                assert st.status == capi.OK and st.n_global > 256
+                assert np.array_equal(x, xf) and np.array_equal(a, af), (rep, runs, K)
+                assert abs(st.residual - rf) <= 1e-12 * max(1.0, rf)
+            x, a, st = solve(ctx, s, rhs, 0.5, method, 300, tol=1e-9)
+            assert st.iterations == it and np.array_equal(x, xt) and np.array_equal(a, at), (rep, runs)
+            pr = capi.Problem(ctx, s.n, s.body0, s.body1, precision=capi.F32)
+            pr.set_blocks(s.Minv, s.J0, s.J1, s.is_eq, s.lo, s.hi, rhs)
+            st = pr.solve(capi.params(method=method, max_iters=12, tol=0.0, cfm=0.05))
+            x, a = pr.lambda_(), pr.accumulators()
+            pr.close()
+            assert st.status == capi.OK
+            assert np.array_equal(x.astype(np.float32), xo32) and np.array_equal(a.astype(np.float32), ao32), (rep, runs)
