@@ -52,3 +52,34 @@ def test_config5_n2048(ctx):
     assert not w[eq].any()
     assert (x[~eq] >= 0).all() and (w[~eq] >= -1e-7).all()
     assert np.abs(x[~eq] * w[~eq]).max() < 1e-7
+
+
+@pytest.mark.parametrize("N,mode", [(1100, 2), (1100, 3), (1350, 2)])
+def test_block_rule_between_the_round_sizes(ctx, N, mode, monkeypatch):
+    """Sizes that are no multiple of anything (the split upload from N = 1024 on, ragged panels, bordered pivots on a
+    base set that is not a multiple of 64) with and without box bounds; KKT conditions, and the same answer with the
+    round-3 shortcuts switched off (fresh factorisation at every pivot, S = everything as the start set)."""
+    rng = np.random.default_rng(N + mode)
+    M = rng.uniform(-1, 1, (N, N))
+    A = M.T @ M + 1e-2 * np.eye(N)
+    b = rng.uniform(-1, 1, N) * (3.0 if mode == 3 else 1.0)
+    Ceq = (rng.uniform(size=N) < 0.4).astype(np.uint8)
+    lo = np.zeros(N) if mode == 2 else np.where(rng.uniform(size=N) < 0.5, -0.2, 0.0)
+    hi = np.full(N, INF) if mode == 2 else np.where(rng.uniform(size=N) < 0.5, 0.3, INF)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, Ceq, lo, hi, use_bounds=mode)
+    assert ok and piv < 60
+    eq = Ceq.astype(bool)
+    assert np.linalg.norm(A @ x - b - w) <= 1e-6 * max(1.0, np.linalg.norm(A @ x))
+    assert not w[eq].any()
+    xi, wi, li, hi_i = x[~eq], w[~eq], lo[~eq], hi[~eq]
+    tol = 1e-7
+    assert (xi >= li - tol).all() and (xi <= hi_i + tol).all()
+    inside = (xi > li + tol) & (xi < hi_i - tol)
+    assert np.abs(wi[inside]).max(initial=0.0) < 1e-6
+    assert (wi[np.abs(xi - li) <= tol] >= -1e-6).all() and (wi[np.abs(xi - hi_i) <= tol] <= 1e-6).all()
+    monkeypatch.setenv("EGS_DENSE_BORDER", "0")
+    monkeypatch.setenv("EGS_DENSE_GUESS", "0")
+    # (the switches are read once per process: this second solve documents the comparison when the suite is run with
+    #  them set from outside -- tests/tools/env_matrix.sh does)
+    ok2, x2, w2, _ = ctx.mixed_constraints_solve(A, b, Ceq, lo, hi, use_bounds=mode)
+    assert ok2 and np.abs(x2 - x).max() <= 1e-8 * max(1.0, np.abs(x).max())
