@@ -1118,6 +1118,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   egs_context *ctx = p->ctx;
   const int n = p->n;
   hipStream_t s = ctx->stream;
+  const auto t_top0 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(s));   // nothing may still read the pinned arena
   ctx->pinned.reset();
   p->m = m;
@@ -1138,8 +1139,11 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
       const int qt = qe ? std::atoi(qe) : 0;
       // 64-constraint tiles when every island fits, else 1024-thread tiles of 256
       // runs (plan.h) while there is about one tile per CU
+      const auto t_pl0 = std::chrono::steady_clock::now();
       p->planq = build_plan(n, m, body0, body1, (qt == 64 || qt == 128 || qt == 256) ? qt : kAutoQuadBlock, &p->planq,
                             p->ctx->cu_count);
+      if (std::getenv("EGS_PLAN_TRACE"))
+        std::fprintf(stderr, "plan trace: build_plan(quad) %.1f us for %d constraints\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pl0).count(), m);
       bool one_round = true;
       if (force != 1 && p->planq.global.empty()) {
         const size_t qlds = (size_t)p->planq.max_slots * 6 * p->real_size();
@@ -1177,6 +1181,8 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
     HIPCHK(hipMemsetAsync(p->wres.p, 0, mm * 3 * rs, s));
   }
   HIPCHK(hipStreamSynchronize(s));
+  if (std::getenv("EGS_PLAN_TRACE"))
+    std::fprintf(stderr, "plan trace: problem_set_topology %.1f us in all\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_top0).count());
   // the 1-lane schedule is built at the first solve that needs it (ensure_tile_plan):
   // its tile size depends on the mass blocks, which arrive after the topology
 }

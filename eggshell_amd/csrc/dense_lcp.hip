@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(1024) murty_advance_kernel(int n, const double
                                                              const int *pos0, const int *idx0, int n0, int *Dl, int *Rl, int list_cap, int seq) {
   __shared__ int s_first, s_last, s_ninf, s_oob, s_wbad, s_improved, s_all, s_flip, s_flipped;
   __shared__ double s_res[1024], s_good[1024];
-  __shared__ int s_scan[1024];
+  __shared__ unsigned long long s_wave[16];
   const int tid = threadIdx.x;
   if (tid == 0) { s_first = 0x7fffffff; s_last = -1; s_ninf = 0; s_oob = 0; s_wbad = 0; s_flipped = 0; }
   __syncthreads();
@@ -834,40 +834,46 @@ __global__ void __launch_bounds__(1024) murty_advance_kernel(int n, const double
     }
   }
   __syncthreads();
-  // the ascending index list of S: thread t owns a run of consecutive indexes
-  const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
-  int cnt = 0;
-  for (int i = i0; i < i1; ++i) cnt += S[i] ? 1 : 0;
-  s_scan[tid] = cnt;
-  __syncthreads();
-  for (int k = 1; k < 1024; k <<= 1) {
-    const int v = tid >= k ? s_scan[tid - k] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
-  int pos = s_scan[tid] - cnt;
-  for (int i = i0; i < i1; ++i) if (S[i]) idx[pos++] = i;
-  const int ns_total = s_scan[1023];
-  // the difference against the factored base set S0 = idx0[0 .. n0): D = S \ S0, R = S0 \ S, ascending (n < 32768).
-  // pos0 is never cleared: an entry counts only if idx0 points back at it.
+  // the ascending index list of S, and the difference against the factored base set S0 = idx0[0 .. n0): D = S \ S0,
+  // R = S0 \ S, ascending.  Thread t owns a run of consecutive indexes; ONE scan over the packed counts (|S| in the low
+  // word, |D| and |R| in 16 bits each: n < 32768 when the base is tracked), inside the wavefronts by shuffles, across them
+  // through LDS.  pos0 is never cleared: an entry counts only if idx0 points back at it.
   auto in_base = [&](int i) { const int q = pos0[i]; return q >= 0 && q < n0 && idx0[q] == i; };
-  int nd_total = -1, nr_total = -1;
-  if (pos0) {
-    int cd = 0, cr = 0;
-    for (int i = i0; i < i1; ++i) { const bool in0 = in_base(i); cd += (S[i] && !in0) ? 1 : 0; cr += (!S[i] && in0) ? 1 : 0; }
-    __syncthreads();
-    s_scan[tid] = cd | (cr << 16);
-    __syncthreads();
-    for (int k = 1; k < 1024; k <<= 1) {
-      const int v = tid >= k ? s_scan[tid - k] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
+  const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
+  unsigned long long mine = 0;
+  for (int i = i0; i < i1; ++i) {
+    const bool in_s = S[i] != 0;
+    mine += in_s ? 1ull : 0ull;
+    if (pos0) {
+      const bool in0 = in_base(i);
+      if (in_s && !in0) mine += 1ull << 32;
+      if (!in_s && in0) mine += 1ull << 48;
     }
-    nd_total = s_scan[1023] & 0xffff; nr_total = s_scan[1023] >> 16;
+  }
+  unsigned long long incl = mine, total = 0;
+  {
+    const int lane = tid & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int k = 0; k < 16; ++k) { if (k < (tid >> 6)) before += s_wave[k]; total += s_wave[k]; }
+    incl += before;
+  }
+  const unsigned long long excl = incl - mine;
+  const int ns_total = (int)(total & 0xffffffffull);
+  int nd_total = -1, nr_total = -1;
+  {
+    int pos = (int)(excl & 0xffffffffull);
+    for (int i = i0; i < i1; ++i) if (S[i]) idx[pos++] = i;
+  }
+  if (pos0) {
+    nd_total = (int)((total >> 32) & 0xffff); nr_total = (int)(total >> 48);
     if (nd_total + nr_total <= list_cap) {
-      int pd = (s_scan[tid] & 0xffff) - cd, pr = (s_scan[tid] >> 16) - cr;
+      int pd = (int)((excl >> 32) & 0xffff), pr = (int)(excl >> 48);
       for (int i = i0; i < i1; ++i) {
         const bool in0 = in_base(i);
         if (S[i] && !in0) Dl[pd++] = i;
@@ -947,9 +953,16 @@ __global__ void __launch_bounds__(256) border_forward_kernel(const double *T, in
 #pragma unroll
     for (int b = 0; b < NJ; ++b) if (w + 4 * b < kBorderJ) acc[b] = __builtin_fma(wv, sU[k][w + 4 * b], acc[b]);
   }
-  double *out = Yp + ((size_t)kbi * n0pad + cb + c) * kBorderStride + j0;
+  // out through LDS: a row's 17 columns are contiguous in Yp, a lane's are not
+  __syncthreads();
 #pragma unroll
-  for (int b = 0; b < NJ; ++b) if (w + 4 * b < kBorderJ) out[w + 4 * b] = acc[b];
+  for (int b = 0; b < NJ; ++b) if (w + 4 * b < kBorderJ) sU[c][w + 4 * b] = acc[b];
+  __syncthreads();
+  double *out = Yp + ((size_t)kbi * n0pad + cb) * kBorderStride + j0;
+  for (int e = threadIdx.x; e < NB * kBorderJ; e += 256) {
+    const int r = e / kBorderJ, j = e % kBorderJ;
+    out[(size_t)r * kBorderStride + j] = sU[r][j];
+  }
 }
 
 // Y = the sum of its tiles' shares for one 64-row block per workgroup, and the block's share of Y'Y (all m + 1 columns:
@@ -1024,7 +1037,10 @@ __global__ void __launch_bounds__(256) border_small_kernel(const double *Cpart, 
     const double piv = M[k][k];
     if (tid == 0 && !(fabs(piv) > 0.0)) atomicOr(fail, 1);
     if (i < m && i != k) {
-      const double f = -M[i][k] / piv;
+      double rp = __builtin_amdgcn_rcp(piv);      // 1 / piv: hardware estimate + two Newton steps
+      rp = __builtin_fma(__builtin_fma(-piv, rp, 1.0), rp, rp);
+      rp = __builtin_fma(__builtin_fma(-piv, rp, 1.0), rp, rp);
+      const double f = -M[i][k] * rp;
       for (int j = k + 1 + ((q - (k + 1)) & 3); j < m1; j += 4) M[i][j] = __builtin_fma(f, M[k][j], M[i][j]);
     }
     __syncthreads();
