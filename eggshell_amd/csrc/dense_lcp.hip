@@ -1641,6 +1641,7 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     return rec->first_offender == 0x7fffffff && !rec->out_of_bounds && !rec->w_bad && std::sqrt(rec->resid2) <= tol;
   };
   int iter = 0, pivots = 0, bordered = 0;
+  bool last_bordered = false;
   bool force = box_fix, solved = false, timed_out = false;
   // the start iterate: its goodness opens the best-solution memory; a box problem solves once before the first flip,
   // the reference's loop (lcp.cc:196-198) checks and flips first
@@ -1674,7 +1675,9 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
       hipLaunchKernelGGL(border_v_kernel, dim3(n0pad / 4), dim3(256), 0, s, Ym.p, n0pad, mb, zz.p, vv.p, Dl.p, nd, dx);
       hipLaunchKernelGGL(inverse_rows_solve_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, T.p, n0pad, n0pad, n0pad, vv.p, n0, idx0.p, dx, S_d.p);
       ++bordered;
+      last_bordered = true;
     } else if (ns > 0) {
+      last_bordered = false;
       hipLaunchKernelGGL(build_pivot_kernel, dim3(grid1((size_t)(2 * nspad + 1) * nspad)), dim3(256), 0, s, dA, n, idx_d.p, ns,
                          nspad, beff.p, T.p, 1, track_base ? pos0.p : (int *)nullptr, idx0.p);
       factor(s, T.p, nspad, 2 * nspad + 1, nspad, fail_d.p, dinv.p, nspad);
@@ -1686,11 +1689,14 @@ bool murty_device(hipStream_t s, int n, const double *dA, const double *db, cons
     hipLaunchKernelGGL(murty_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dA, n, dx, db, S_d.p, r.p, dw);
     ++pivots;
     advance(flip_mode, 1e-9, 1);     // lcp.cc:125-137: the best iterate by "goodness" is kept by the kernel
+    // resid2 is the squared residual of A(S,S) x(S) = b(S) (w is zero on S, r - w off it): a bordered solve that misses
+    // the tolerance a solution must meet anyway is not built upon -- the next pivot factors afresh
+    if (last_bordered && !(std::sqrt(rec->resid2) <= 1e-10)) base_n0 = -1;
     if (trace) {
       const auto t_now = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d (%s, +%d -%d against the factored set), %.3f ms; then %d infeasible, %d flipped\n",
-                   pivots, ns, n, (track_base && base_n0 > 0 && nd >= 0 && mb <= kBorderMax && ns > 0) ? "bordered" : "factored", nd, nr,
-                   std::chrono::duration<double, std::milli>(t_now - t_prev).count(), rec->ninf, rec->flipped);
+      std::fprintf(stderr, "dense trace pivot %d: ns %d of %d (%s, +%d -%d against the factored set), %.3f ms, residual on S %.1e; then %d infeasible, %d flipped\n",
+                   pivots, ns, n, last_bordered ? "bordered" : "factored", nd, nr,
+                   std::chrono::duration<double, std::milli>(t_now - t_prev).count(), std::sqrt(rec->resid2), rec->ninf, rec->flipped);
       t_prev = t_now;
     }
     ++iter;

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
@@ -325,8 +327,22 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
 }
 }  // namespace
 
+namespace {
+struct PhaseClock {      // EGS_PLAN_PHASES=1: where build_plan's time goes (stderr)
+  bool on = std::getenv("EGS_PLAN_PHASES") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "plan phase %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
+
 Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
                 int block, Plan *recycle, int max_run_tiles) {
+  PhaseClock phase_clock;
   if (n_bodies < 0 || m < 0 || block < 0 || block > 1024)
     throw std::invalid_argument("build_plan: bad sizes");
   Plan plan;
@@ -381,6 +397,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   }
   const int n_chunks = (int)chunk_len.size();
 
+  phase_clock.mark("recycle + runs");
   // 1. islands: union bodies that share a constraint.
   UnionFind uf(n_bodies);
   for (int i = 0; i < m; ++i)
@@ -430,6 +447,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     plan.block = block;
   }
 
+  phase_clock.mark("islands");
   // 2. per-body rank (pos) and count (cnt) in list order.
   std::vector<int32_t> cnt(n_bodies, 0), pos0(m, 0), pos1(m, 0);
   for (int i = 0; i < m; ++i) {
@@ -458,6 +476,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   }
   plan.n_tiles = (int)tile_fill.size();
 
+  phase_clock.mark("rank + tiles");
   // lane order inside a tile.  In the pipelined sweep constraint i runs at time
   // ~ level(i) + D * sweep, level = depth in the list-order dependency DAG and
   // D = the largest per-body constraint count of its island (the ticket period).
@@ -510,6 +529,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
       }
     }
   }
+  phase_clock.mark("levels + phases");
   // order by (phase, island, list index): stable counting sort -- one pass on the combined
   // key when that needs few buckets, else two passes (LSD radix)
   std::vector<int32_t> order(m);
@@ -535,6 +555,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     }
   }
 
+  phase_clock.mark("order");
   LaneDesc idle{};
   idle.cidx = -1;
   plan.lanes.assign((size_t)plan.n_tiles * block, idle);
@@ -718,6 +739,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   for (int b = 0; b < n_bodies; ++b)
     if (body_tile[b] >= 0) plan.slot_body[(size_t)plan.tile_slot_off[body_tile[b]] + body_slot[b]] = b;
 
+  phase_clock.mark("lanes + slots");
   // 4. oversize islands, in list order.
   for (int i = 0; i < m; ++i) {
     if (island_tile[cons_island[i]] != -2) continue;
@@ -728,6 +750,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     g.pos1 = pos1[i]; g.cnt1 = body1[i] >= 0 ? cnt[body1[i]] : 0;
     plan.global.push_back(g);
   }
+  phase_clock.mark("global list");
   if (!plan.global.empty()) {
     build_patches(plan, n_bodies, body0, body1, cnt, pos0, pos1, true);
     if (plan.patch_runs && plan.n_patch_tiles > g_patch_workgroups) {
@@ -738,6 +761,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
     }
     if (plan.n_patch_tiles == 0) plan.patch_runs = false;
   }
+  phase_clock.mark("patches");
   return plan;
 }
 
