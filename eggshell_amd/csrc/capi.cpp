@@ -775,7 +775,8 @@ egs_status do_solve(egs_problem *p, const egs_solve_params *prm, egs_solve_stats
     // the snapshots are scratch of THIS call: a problem object that once ran a tolerance-terminated solve on a large
     // system must not keep up to 2 GiB of HBM (and the page-locked mirror) for the rest of its life.  Small ones stay
     // (a converging Chain re-solves every step); the stream-ordered free waits for the kernels above.
-    if (p->hist_x.bytes() + p->hist_acc.bytes() > (size_t(256) << 20)) {
+    static const size_t keep_mb = [] { const char *e = std::getenv("EGS_HIST_KEEP_MB"); return e ? (size_t)std::atol(e) : (size_t)256; }();
+    if (p->hist_x.bytes() + p->hist_acc.bytes() > (keep_mb << 20)) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
       p->hist_x.release(); p->hist_acc.release(); p->hist_out.release();
     }
