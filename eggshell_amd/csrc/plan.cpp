@@ -564,6 +564,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
   plan.tile_depth.assign(plan.n_tiles, 1);
   plan.tile_nslots.assign(plan.n_tiles, 1);
   plan.tile_slot_off.assign(plan.n_tiles, 0);
+  phase_clock.mark("  assigns");
   std::vector<int32_t> lane_fill(plan.n_tiles, 0);
   std::vector<int32_t> body_slot(n_bodies, -1), body_tile(n_bodies, -1);
   std::vector<int32_t> lane_src;      // runs: the constraint whose bodies a lane slot (member or placeholder) belongs to
@@ -618,6 +619,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
         }
     }
   }
+  phase_clock.mark("  lanes");
   // LDS slots.  A slot's number decides its banks: the ticket word s_tick[slot] is polled with
   // ds_read_b32 (bank = slot mod 32, the 32 lanes of a half-wave share a pass) and the 48-byte
   // accumulator is read as three ds_read_b128 (16-byte piece 3*slot+k mod 16, passes of 16 lanes:
@@ -700,6 +702,7 @@ Plan build_plan(int n_bodies, int m, const int32_t *body0, const int32_t *body1,
       }
     }
   }
+  phase_clock.mark("  slots");
   if (const char *e = std::getenv("EGS_PLAN_STATS"); e && std::atoi(e) != 0) {
     // modelled extra LDS cycles with every lane active: distinct slots on one bank within a pass
     long tick_extra = 0, acc_extra = 0, passes = 0;
