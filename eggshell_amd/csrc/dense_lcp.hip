@@ -1743,6 +1743,11 @@ bool dense_mixed_constraints(hipStream_t s, int N, const double *A, const double
   // Schur stage reads -- and the rest follows on a second stream while the device factors.
   const int chunk = N >= 1024 ? ((N / 4 + 63) / 64) * 64 : 0;
   hipStream_t side = nullptr;
+  // whatever way this call ends, dA goes back to the scratch cache only after the side stream is done with it
+  struct SideGuard {
+    hipStream_t *q;
+    ~SideGuard() { if (*q) (void)hipStreamSynchronize(*q); }
+  } side_guard{&side};
   std::function<void()> rest;
   if (chunk) {
     side = side_stream();
