@@ -409,8 +409,8 @@ __global__ void __launch_bounds__(1024) back_solve_kernel(const double *T, int l
     // The strip L[kb .. kb+64)[0 .. kb) is subtracted from the kb open entries by P threads per column (P rows-parts of
     // R = 64 / P rows, as many as 1024 threads allow); its entries do not depend on x_k, so they are requested now and
     // arrive while x_k = L_kk^-T t_k is formed.
-    int P = kb > 0 ? 1024 / kb : 0;
-    P = P >= 16 ? 16 : P >= 8 ? 8 : P >= 4 ? 4 : P >= 2 ? 2 : P;
+    int P = kb > 0 ? 1024 / kb : 0;      // (0 only for kb = 0: more than 1024 open columns is P = 1 plus the tail loop below)
+    P = P >= 16 ? 16 : P >= 8 ? 8 : P >= 4 ? 4 : P >= 2 ? 2 : (kb > 0 ? 1 : 0);
     const int R = P ? NB / P : 0;
     const bool active = P > 0 && tid < P * kb;
     const int c = active ? tid % kb : 0, rp = active ? tid / kb : 0;

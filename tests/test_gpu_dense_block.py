@@ -83,3 +83,21 @@ def test_block_rule_between_the_round_sizes(ctx, N, mode, monkeypatch):
     #  them set from outside -- tests/tools/env_matrix.sh does)
     ok2, x2, w2, _ = ctx.mixed_constraints_solve(A, b, Ceq, lo, hi, use_bounds=mode)
     assert ok2 and np.abs(x2 - x).max() <= 1e-8 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("N,eq_frac", [(1200, 1.0), (1400, 0.9), (2300, 1.0)])
+def test_many_equality_rows(ctx, N, eq_frac):
+    """More than 1 024 equality rows: the Schur stage's back substitution has more open columns than its workgroup has
+    threads (found by tools/dense_fuzz.py: the strip update skipped them)."""
+    rng = np.random.default_rng(N)
+    M = rng.uniform(-1, 1, (N, N))
+    A = M.T @ M + 1e-2 * np.eye(N)
+    b = rng.uniform(-1, 1, N)
+    Ceq = (rng.uniform(size=N) < eq_frac).astype(np.uint8)
+    ok, x, w, piv = ctx.mixed_constraints_solve(A, b, Ceq, np.zeros(N), np.full(N, INF), use_bounds=2)
+    assert ok
+    eq = Ceq.astype(bool)
+    assert np.abs(A @ x - b - w).max() <= 1e-7 * max(1.0, np.abs(A @ x).max())
+    assert not w[eq].any() and (x[~eq] >= -1e-9).all() and (w[~eq] >= -1e-7).all()
+    if eq.all():
+        assert np.abs(x - np.linalg.solve(A, b)).max() <= 1e-7 * max(1.0, np.abs(x).max())
