@@ -267,6 +267,11 @@ struct egs_problem {
   DevBuf<unsigned char> tmp_rows;   // [3m] REAL scratch
   DevBuf<double> dense_A;        // J M^-1 J^T + cfm I of the dense path (egs_problem_dense_system), [3m][3m]
   double dense_cfm = -1.0;       // the cfm dense_A was built with (< 0: not built)
+  // row types and bounds of the assembled system on the host (the dense path partitions by them): they depend on the
+  // constraint kinds only (joints.cc:13-35, contact.cc:103-113), so they are read back once per set of kinds
+  std::vector<uint8_t> h_rows_eq;
+  std::vector<double> h_rows_lo, h_rows_hi;
+  bool h_rows_valid = false;
   bool minv_iso = false;       // every M^-1 block is diag(a,a,a,b,b,b): the tile kernel keeps no B (EGS_ISO=0 disables)
   int last_iterations = 0;
   size_t real_size() const { return precision == EGS_F32 ? sizeof(float) : sizeof(double); }
@@ -1153,6 +1158,7 @@ void problem_set_topology(egs_problem *p, int32_t m, const int32_t *body0, const
   p->tile_plan_ready = false;
   p->mv_ready = false;
   p->dense_cfm = -1.0;
+  p->h_rows_valid = false;
   p->use_quad = false;
   p->have_blocks = false;
   p->have_constraints = false;
@@ -1397,6 +1403,7 @@ egs_status egs_problem_set_constraints(egs_problem *p, const int32_t *kind, cons
     upload(p->kind, kind, (size_t)p->m, p->ctx->stream);
     upload(p->data, data, (size_t)p->m * 7, p->ctx->stream);
     p->have_constraints = true;
+    p->h_rows_valid = false;
     return EGS_OK;
   });
 }
@@ -1654,12 +1661,16 @@ egs_status egs_problem_step_dense(egs_problem *p, double dt, double erp, double 
     }
     if (egs_status st = build_dense_system(p, cfm)) return st;   // ensembles.cc:510, 513-521
     const size_t rows = (size_t)p->m * 3;
-    std::vector<uint8_t> C(rows);
-    std::vector<double> lo(rows), hi(rows);
-    HIPCHK(hipMemcpyAsync(C.data(), p->is_eq.p, rows, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(lo.data(), p->lo.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hi.data(), p->hi.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (!p->h_rows_valid || p->h_rows_eq.size() != rows) {
+      p->h_rows_eq.resize(rows); p->h_rows_lo.resize(rows); p->h_rows_hi.resize(rows);
+      HIPCHK(hipMemcpyAsync(p->h_rows_eq.data(), p->is_eq.p, rows, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(p->h_rows_lo.data(), p->lo.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(p->h_rows_hi.data(), p->hi.p, rows * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      p->h_rows_valid = true;
+    }
+    const std::vector<uint8_t> &C = p->h_rows_eq;
+    const std::vector<double> &lo = p->h_rows_lo, &hi = p->h_rows_hi;
     int piv = 0;
     std::string msg;
     // Lcp::MixedConstraintsSolver (ensembles.cc:531) on the device matrix; lambda lands in the problem's x
@@ -1985,6 +1996,7 @@ void world_make_problem(egs_world *w, const int32_t *b0, const int32_t *b1, int 
     if (mj > 0) upload(np->data, w->jdata.data(), (size_t)mj * 7, s);
   }
   np->have_constraints = true;
+  np->h_rows_valid = false;
   w->topo_b0.assign(b0, b0 + m); w->topo_b1.assign(b1, b1 + m);
   ++w->replans;
 }

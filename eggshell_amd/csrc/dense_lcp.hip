@@ -2004,17 +2004,19 @@ bool dense_mixed_impl(hipStream_t s, int N, const double *dA_in, const double *d
       std::fprintf(stderr, "dense trace schur: ne %d ni %d, symmetry + factor + first check %.3f ms\n", ne, ni,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dev0).count());
   };
-  if (ni == 0) { HIPCHK(hipStreamSynchronize(s)); deferred(); }
+  // (no inequality rows: nothing synchronises before the final read-back, the checks run there)
   // Murty on the inequality part; the reference calls the no-bounds overload (lcp.cc:298)
   std::vector<double> l2(ni), h2(ni);
   for (int k = 0; k < ni; ++k) { l2[k] = use_bounds ? lo[I[k]] : 0.0; h2[k] = use_bounds ? hi[I[k]] : std::numeric_limits<double>::infinity(); }
   int piv = 0;
-  bool deferred_ran = ni == 0;
+  bool deferred_ran = false;
   const std::function<void()> once = [&]() { if (!deferred_ran) { deferred_ran = true; deferred(); } };
   bool ok = true;
-  if (!schur_failed) ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, max_pivots, max_seconds, xi.p, wi.p, &piv, msg, fail_d.p, &once);
-  once();     // (paths of the pivot loop that return without its first synchronisation hook have synchronised all the same)
-  if (schur_failed) { if (msg) *msg = "A_ee is not positive definite"; return false; }
+  if (ni > 0) {
+    ok = murty_device(s, ni, lhs.p, rhs.p, l2, h2, use_bounds, block_pivoting, max_pivots, max_seconds, xi.p, wi.p, &piv, msg, fail_d.p, &once);
+    once();     // (paths of the pivot loop that return without its first synchronisation hook have synchronised all the same)
+    if (schur_failed) { if (msg) *msg = "A_ee is not positive definite"; return false; }
+  }
   if (pivots) *pivots = piv;
   if (!ok) return false;
   // x_e = A_ee^-1 (b_e - A_ei x_i) = L^-T (L^-1 b_e - (L^-1 A_ei) x_i)   (lcp.cc:317)
@@ -2034,6 +2036,8 @@ bool dense_mixed_impl(hipStream_t s, int N, const double *dA_in, const double *d
   HIPCHK(hipMemcpyAsync(xwh.data(), xw.p, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost, s));
   if (dx_out) HIPCHK(hipMemcpyAsync(dx_out, xw.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));   // stays on the device too
   HIPCHK(hipStreamSynchronize(s));
+  once();
+  if (schur_failed) { if (msg) *msg = "A_ee is not positive definite"; return false; }
   if (x) std::memcpy(x, xwh.data(), (size_t)N * sizeof(double));
   if (w) std::memcpy(w, xwh.data() + N, (size_t)N * sizeof(double));
   return true;
