@@ -534,8 +534,9 @@ def c5_leg(ctx, cpu_seconds):
                      "includes": "upload + one single-wavefront launch + download (toolkit/lcp.cc:213-619 semantics, A permuted in place)"}
     out["note"] = ("reference_rule = Murty single-index principal pivoting as lcp.cc:157-274 (cap min(1000, 2^n) pivots: it "
                    "cannot finish N >= 1024 mixed problems, in the reference as here); block_pivoting = same solution, tens of "
-                   "factorisations.  Launch-bound at these sizes: ~3 dependent launches per 64-column panel; fp64 MFMA peak is "
-                   "not in the local guides, so TFLOP/s is reported, not a fraction")
+                   "factorisations, starting from the set the diagonal suggests; pivots that move <= 64 indexes solve a bordered "
+                   "system on the previous factor.  Latency-bound at these sizes: one launch of ~23 us per 64-column panel (the "
+                   "diagonal tile's column chain); fp64 MFMA peak is not in the local guides, so TFLOP/s is reported, not a fraction")
     if cpu_seconds > 0:
         cpu = {}
         for N in (256, 512):
