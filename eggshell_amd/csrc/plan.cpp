@@ -56,7 +56,11 @@ void build_patches(Plan &plan, int n_bodies, const int32_t *body0, const int32_t
     if (forced >= 16 && forced <= block) cap = forced;
     else if (block >= 128) {
       const int target = (int)((mg + (long)(g_patch_workgroups * 9 / 10) - 1) / std::max(1, g_patch_workgroups * 9 / 10));
-      cap = std::min(cap, std::max(48, (target + 15) / 16 * 16));
+      // (with runs -- chunks of four as one node, below -- a patch's own work is cheaper against a crossing: walls of
+      //  1 080 / 10 376 / 16 404 contacts are fastest at 128 / 80-96 / 96 slots per patch, measured)
+      const char *re = std::getenv("EGS_PATCH_RUNS");
+      const int floor_cap = (allow_runs && block == 256 && !(re && std::atoi(re) == 0)) ? 96 : 48;
+      cap = std::min(cap, std::max(floor_cap, (target + 15) / 16 * 16));
     }
   }
   // owner body of a constraint = its first real body
